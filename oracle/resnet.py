@@ -1,0 +1,93 @@
+"""Functional CPU restatement of the classifier (TEST INFRASTRUCTURE, not product).
+
+Follows ``/root/reference/src/model.py``: ``CoughDetectorResidual.forward``
+(:253-259), ``ResidualBlock.forward`` (:285-293), ``predict`` (:261-265), with
+eval-mode BatchNorm (running stats, eps 1e-5) and Dropout = identity.  Takes
+the reference's own ``state_dict`` (keys listed in SURVEY.md section 8a M0).
+PINNED: ``tests/test_oracle_resnet.py`` checks it against goldens produced by
+running the reference module itself (``oracle/make_golden.py``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+
+
+def _bn(x, sd, prefix):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=EPS)
+
+
+def stem(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """M1 -- model.py:227-232: conv7x7 s2 p3 -> BN -> ReLU -> maxpool 2."""
+    y = F.conv2d(x, sd["conv1.0.weight"], sd["conv1.0.bias"], stride=2, padding=3)
+    return F.max_pool2d(F.relu(_bn(y, sd, "conv1.1")), 2)
+
+
+def res_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int) -> torch.Tensor:
+    """M2/M3 -- model.py:285-293 with the projection skip of :280-283."""
+    p = f"res_blocks.{i}"
+    identity = _bn(F.conv2d(x, sd[p + ".skip.0.weight"], sd[p + ".skip.0.bias"], stride=2), sd, p + ".skip.1")
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=2, padding=1), sd, p + ".bn1"))
+    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1), sd, p + ".bn2")
+    return F.relu(out + identity)
+
+
+def head(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """M4 -- model.py:242-247,257-258: global mean -> Linear(128, 2)."""
+    return F.linear(x.mean(dim=(2, 3)), sd["fc.2.weight"], sd["fc.2.bias"])
+
+
+def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], return_intermediates: bool = False):
+    a1 = stem(x, sd)
+    a2 = res_block(a1, sd, 0)
+    a3 = res_block(a2, sd, 1)
+    logits = head(a3, sd)
+    if return_intermediates:
+        return logits, (a1, a2, a3)
+    return logits
+
+
+def predict(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """M5 -- model.py:261-265."""
+    probs = F.softmax(forward(x, sd), dim=1)
+    return probs.argmax(dim=1), probs
+
+
+def random_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """A state_dict with the reference's key set / shapes and NON-trivial BN
+    statistics (fresh-init 0/1 stats would not exercise BN folding)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, co, ci, k):
+        bound = 1.0 / (ci * k * k) ** 0.5
+        sd[name + ".weight"] = (torch.rand(co, ci, k, k, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=g) + 0.5
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.2
+        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.2
+        sd[name + ".running_var"] = torch.rand(c, generator=g) * 1.5 + 0.25
+        sd[name + ".num_batches_tracked"] = torch.tensor(100)
+
+    conv("conv1.0", 32, 1, 7)
+    bn("conv1.1", 32)
+    ci = 32
+    for i, co in enumerate((64, 128)):
+        p = f"res_blocks.{i}"
+        conv(p + ".conv1", co, ci, 3)
+        bn(p + ".bn1", co)
+        conv(p + ".conv2", co, co, 3)
+        bn(p + ".bn2", co)
+        conv(p + ".skip.0", co, ci, 1)
+        bn(p + ".skip.1", co)
+        ci = co
+    sd["fc.2.weight"] = (torch.rand(2, 128, generator=g) * 2 - 1) / 128 ** 0.5
+    sd["fc.2.bias"] = (torch.rand(2, generator=g) * 2 - 1) / 128 ** 0.5
+    return sd

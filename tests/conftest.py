@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when collected on a box without a GPU."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def resnet_golden():
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(GOLDEN, "resnet_golden.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    vec = {k: torch.from_numpy(g[k]) for k in g.files if not k.startswith("sd.")}
+    return sd, vec
+
+
+@pytest.fixture(scope="session")
+def features_golden():
+    import numpy as np
+    g = np.load(os.path.join(GOLDEN, "features_golden.npz"))
+    return {k: g[k] for k in g.files}

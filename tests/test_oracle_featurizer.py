@@ -1,0 +1,135 @@
+"""Pins for the CPU featuriser oracle: independent float64
+re-derivation, third-party table cross-checks, analytic known answers, golden regression."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from cough_detector_amd import synth
+from oracle import dft64, featurizer as F
+
+
+def test_shapes_match_reference_contract():
+    # get_expected_time_frames() = 16000//160+1 = 101 (preprocessing.py:532-534); 64+13+13 = 90 (:536-550)
+    x = torch.from_numpy(synth.make_clip(3))[None]
+    f = F.extract_features(x)
+    assert f.shape == (1, 90, 101) and f.dtype == torch.float32
+    assert F.extract_features(x, use_delta_delta=True).shape == (1, 103, 101)
+
+
+def test_filterbank_against_transformers_and_float64():
+    fb = F.melscale_fbanks().numpy()
+    assert fb.shape == (257, 64)
+    ref64 = dft64.mel_fb()
+    assert np.abs(fb - ref64).max() < 1e-5
+    nz = np.nonzero(fb.sum(axis=1))[0]
+    assert nz.min() >= 4 and nz.max() <= 127          # only bins 4..127 feed the mel bands
+    assert ((fb > 0).sum(axis=0) >= 1).all() and (fb > 0).sum(axis=0).max() <= 8
+    tr = pytest.importorskip("transformers.audio_utils")
+    tfb = tr.mel_filter_bank(257, 64, 100.0, 4000.0, 16000, norm=None, mel_scale="htk")
+    assert np.abs(fb - tfb).max() < 1e-5
+
+
+def test_dct_against_scipy():
+    from scipy.fft import dct
+    d = F.create_dct().numpy()                          # (64, 13)
+    ref = dct(np.eye(64), type=2, norm="ortho", axis=0)[:13].T
+    assert np.abs(d - ref).max() < 1e-6
+    assert np.abs(d - dft64.dct_ortho()).max() < 1e-6
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 13])
+def test_stft_power_against_float64_framing(seed):
+    x = synth.make_clip(seed)
+    p32 = F.stft_power(torch.from_numpy(x)[None])[0].numpy()
+    p64 = dft64.stft_power(x)
+    assert p32.shape == p64.shape == (257, 101)
+    scale = p64.max(axis=0, keepdims=True)              # per-frame full scale
+    assert (np.abs(p32 - p64) / scale).max() < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_features_against_float64(seed):
+    x = synth.make_clip(seed)
+    f32 = F.extract_features(torch.from_numpy(x)[None])[0].numpy()
+    f64 = dft64.features(x)
+    assert np.abs(f32[:64] - f64[:64]).max() < 1e-5
+    assert np.abs(f32[64:] - f64[64:]).max() < 2e-5
+
+
+def test_known_answer_silence():
+    # all-zero clip: power 0 -> clamp amin -> dB = -100 everywhere, floor = -180 (inactive),
+    # mel rows clamp to exactly 0; MFCC c0 = -100*64*sqrt(1/64) = -800 before the z-score.
+    x = torch.zeros(1, 16000)
+    db = F.amplitude_to_db(F.mel_spectrogram(x))
+    assert torch.all(db == -100.0)
+    m = F.mfcc_transform(x)
+    assert torch.allclose(m[0, 0], torch.full((101,), -800.0), atol=1e-3)
+    f = F.extract_features(x)
+    assert torch.all(f[0, :64] == 0) and torch.isfinite(f).all()
+    assert F.normalize(x) is x                          # silent no-op on all-zero input (:209-212)
+
+
+def test_known_answer_bin_centred_sine():
+    # 1000 Hz = bin 32 exactly; interior frames: |X[32]|^2 = (sum(w)/2)^2 = 100^2
+    t = np.arange(16000) / 16000.0
+    x = torch.from_numpy(np.sin(2 * np.pi * 1000.0 * t).astype(np.float32))[None]
+    p = F.stft_power(x)[0]
+    assert torch.allclose(p[32, 5:95], torch.full((90,), 1.0e4), rtol=1e-4)
+
+
+def test_known_answer_impulse():
+    # unit impulse at n0: frames containing it have a flat spectrum of w[n]^2
+    x = torch.zeros(1, 16000)
+    x[0, 8000] = 1.0
+    p = F.stft_power(x)[0].numpy()
+    w = dft64.window512()
+    for t in (49, 50, 51):
+        pos = 8000 + 256 - 160 * t
+        assert np.allclose(p[:, t], w[pos] ** 2, rtol=1e-4, atol=1e-9)
+
+
+def test_delta_of_ramp():
+    r = torch.arange(101, dtype=torch.float32).reshape(1, 1, 101) * 3.0
+    d = F.compute_deltas(r)
+    assert torch.allclose(d[0, 0, 1:-1], torch.full((99,), 3.0))
+    assert d[0, 0, 0] == 1.5 and d[0, 0, -1] == 1.5
+
+
+def test_top_db_is_per_clip():
+    loud = torch.from_numpy(synth.make_clip(2))[None]
+    quiet = loud * 1e-4
+    both = torch.cat([loud, quiet])
+    per_clip = F.extract_features_batch(both)
+    assert torch.equal(per_clip[1], F.extract_features(quiet)[0])
+    fast = F.extract_features_batched_fast(both)
+    assert torch.allclose(fast, per_clip, atol=2e-5)
+
+
+def test_batched_fast_matches_loop():
+    w = torch.from_numpy(synth.make_clips(0, 12, peak_normalize=False))
+    a = F.extract_features_batch(w, normalize_first=True)
+    b = F.extract_features_batched_fast(w, normalize_first=True)
+    assert (a[:, :64] - b[:, :64]).abs().max() < 2e-5
+    assert (a[:, 64:] - b[:, 64:]).abs().max() < 1e-4
+
+
+def test_golden_regression(features_golden):
+    wav = synth.make_clips(0, 12)
+    crc = np.array([zlib.crc32(w.tobytes()) for w in wav], dtype=np.uint32)
+    assert np.array_equal(crc, features_golden["wav_crc32"]), "synthetic clip generator drifted"
+    f = F.extract_features_batch(torch.from_numpy(wav)).numpy()
+    assert np.abs(f - features_golden["features"]).max() < 5e-5
+
+
+def test_realtime_windower_counts():
+    w = F.RealtimeWindowerOracle(window_duration=1.0, hop_duration=0.25)
+    stream = torch.from_numpy(synth.make_stream(1, 2.0))
+    n = 0
+    for i in range(0, stream.numel(), 1600):
+        n += len(w.add_audio(stream[i:i + 1600]))
+    assert n == 5                                       # windows end at 1.0,1.25,...,2.0 s
+    assert w.buffer.shape[1] == 32000 - 5 * 4000
+    w.reset()
+    assert w.buffer.shape == (1, 0)
