@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1 s @ 16 kHz clips/s through featurise (K1) + CoughDetectorResidual (K2-K5).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step is one pass of the hot path over one batch of B = 4096 synthetic clips that are already
+resident in HBM (BASELINE.json configs[2]).  With N ranks the clip stream is sharded round-robin
+(clip i -> rank i mod N, weak scaling: every rank runs B clips per step) and the only exchange is
+an RCCL all-gather of the (B, 2) logits per step.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line: ``roofline`` (featurise kernel vs HBM: algorithmic 100 360 B/clip over
+the kernel's HIP-event time inside the timed region), ``roofline_classifier`` (42.87 MFLOP/clip vs
+the dense MFMA peak of the compute dtype) and ``cpu_baseline`` (the torch-CPU oracle timed on this
+box's host cores on a bounded sample; rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CLIP = 64000 + 36360          # waveform read + (90,101) f32 written
+FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+
+
+def cpu_baseline(budget_s: float) -> dict:
+    """Reference-faithful CPU path (per-clip loop, batch 1, STFT computed twice, softmax(...).item(),
+    as src/preprocessing.py:398,425 + src/inference.py:216-217) and a best-effort batched CPU path,
+    both from oracle/ (kind "port": the reference's own preprocessing.py needs torchaudio, absent here)."""
+    from cough_detector_amd import synth
+    from oracle import featurizer as ofeat, resnet as ores
+    sd = synth.random_state_dict(seed=3)
+    threads = torch.get_num_threads()
+    wav = torch.from_numpy(synth.make_clips(0, 256, peak_normalize=False))
+    with torch.no_grad():
+        for i in range(8):                                                  # warm-up
+            f = ofeat.extract_features(ofeat.normalize(wav[i:i + 1]))
+            torch.softmax(ores.forward(f.unsqueeze(0), sd), dim=1)[0, 1].item()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            w = wav[n % 256:n % 256 + 1]
+            f = ofeat.extract_features(ofeat.normalize(w))
+            torch.softmax(ores.forward(f.unsqueeze(0), sd), dim=1)[0, 1].item()
+            n += 1
+        faithful = n / (time.perf_counter() - t0)
+        ofeat.extract_features_batched_fast(wav, normalize_first=True)      # warm-up
+        m, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 2:
+            f = ofeat.extract_features_batched_fast(wav, normalize_first=True)
+            torch.softmax(ores.forward(f.unsqueeze(1), sd), dim=1)
+            m += 256
+        batched = m / (time.perf_counter() - t0)
+    return {"value": round(faithful, 1), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{n} clips, per-clip loop (batch 1, duplicated STFT, softmax.item()) on synthetic 1 s clips; "
+                      f"torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical cores",
+            "batched_value": round(batched, 1),
+            "batched_sample": f"{m} clips at batch 256, single STFT, all threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="clips per rank per step")
+    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--featurize-only", action="store_true", help="time K1 alone (BASELINE configs[1])")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cough_detector_amd as cda
+    from cough_detector_amd import synth
+    from cough_detector_amd.distributed import gather_logits_round_robin
+
+    B, K, W = args.batch, args.steps, args.warmup
+    # rank r owns global clips r, r+N, r+2N, ... (round-robin); synthetic, regenerated from the clip index
+    wav = torch.from_numpy(synth.make_clips(rank, B, stride=world, peak_normalize=False)).to(dev)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=args.dtype)
+    model.load_state_dict(synth.random_state_dict(seed=3))
+    model.to(dev).eval()
+    feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if world > 1 else None
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+
+    def step(i, timed):
+        if timed:
+            ev[i][0].record()
+        pre.featurize_batch(wav, normalize=True, out=feats)
+        if timed:
+            ev[i][1].record()
+        if args.featurize_only:
+            return None
+        logits = model(feats.unsqueeze(1))
+        if timed:
+            ev[i][2].record()
+        if world > 1:
+            return gather_logits_round_robin(logits, out=gathered)
+        return logits
+
+    for i in range(W):
+        step(i, False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        out = step(i, True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / K
+    net_ms = 0.0 if args.featurize_only else sum(e[1].elapsed_time(e[2]) for e in ev) / K
+
+    if rank == 0:
+        total_clips = world * B * K
+        achieved = B * BYTES_PER_CLIP / (k1_ms * 1e-3) / 1e9
+        line = {
+            "metric": "1s@16kHz clips/sec (featurise+infer)" if not args.featurize_only
+                      else "1s@16kHz clips/sec (featurise only)",
+            "value": round(total_clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.featurize_only else
+                                           ("bf16 conv (f32 features/stem/accumulate)" if args.dtype == "bf16" else "f32"),
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: batch=4096 synthetic 1s@16kHz mono per GPU -> 90x101 features "
+                                   "(64 mel + 13 MFCC + 13 delta, f32) -> CoughDetectorResidual logits"
+                                   if not args.featurize_only else
+                                   "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32",
+                       "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
+                       "collective": "all_gather(logits) per step" if world > 1 else "none",
+                       "weights": "random-init, BN stats randomised"},
+            "roofline": {"kernel": "featurize_kernel (K1)", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "ms_per_launch": round(k1_ms, 4),
+                         "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP},
+        }
+        if not args.featurize_only:
+            tf = B * FLOP_PER_CLIP / (net_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            line["roofline_classifier"] = {"kernel": "stem+conv_mfma x4+tail (K2-K5)", "bound": "mfma",
+                                           "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                           "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4)}
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

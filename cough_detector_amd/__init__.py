@@ -1,0 +1,9 @@
+"""MI355X-native (gfx950) hot path of the cough detector: audio featuriser + CoughDetectorResidual
+forward + sliding-window engine, behind the reference's Python call surface.  All arithmetic runs in
+hand-written HIP kernels (``csrc/``) reached through the C-ABI in ``include/cough_amd.h``."""
+from .preprocessing import AudioPreprocessor, RealtimePreprocessor, create_preprocessor
+from .model import CoughDetectorResidual, ResidualBlock, create_model, count_parameters
+from .inference import CoughDetectorInference
+
+__all__ = ["AudioPreprocessor", "RealtimePreprocessor", "create_preprocessor", "CoughDetectorResidual",
+           "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference"]

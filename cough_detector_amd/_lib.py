@@ -1,0 +1,110 @@
+"""ctypes binding of ``libcough_amd.so`` (the C-ABI declared in ``include/cough_amd.h``).
+
+There is no CPU fallback: if the shared object is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcough_amd.so")
+
+OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
+FEAT_NORMALIZE = 1
+DTYPE_FP32, DTYPE_BF16, _DTYPE_DIRECT = 0, 1, 2
+DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT}
+
+# every symbol include/cough_amd.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "cough_amd_abi_version", "cough_amd_arch", "cough_amd_last_error",
+    "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
+    "cough_featurizer_num_frames", "cough_featurize",
+    "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
+    "cough_resnet_forward", "cough_resnet_read_activation",
+    "cough_ring_write", "cough_window_gather",
+)
+
+
+class FeatConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("n_fft", C.c_int), ("hop_length", C.c_int), ("win_length", C.c_int),
+                ("n_mels", C.c_int), ("n_mfcc", C.c_int), ("segment_samples", C.c_int),
+                ("use_pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float), ("use_delta_delta", C.c_int)]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class ConvBN(C.Structure):
+    _fields_ = [("w", _FP), ("b", _FP), ("bn_w", _FP), ("bn_b", _FP), ("bn_mean", _FP), ("bn_var", _FP)]
+
+
+class ResBlockWeights(C.Structure):
+    _fields_ = [("conv1", ConvBN), ("conv2", ConvBN), ("skip", ConvBN)]
+
+
+class ResNetWeights(C.Structure):
+    _fields_ = [("stem", ConvBN), ("block", ResBlockWeights * 2), ("fc_w", _FP), ("fc_b", _FP), ("bn_eps", C.c_float)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m cough_detector_amd.build` "
+                "(needs hipcc / ROCm, target gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        vp, ll, i = C.c_void_p, C.c_longlong, C.c_int
+        lib.cough_amd_abi_version.restype = i
+        lib.cough_amd_arch.restype = C.c_char_p
+        lib.cough_amd_last_error.restype = C.c_char_p
+        lib.cough_featurizer_create.argtypes = [C.POINTER(vp), C.POINTER(FeatConfig), _FP, _FP, _FP]
+        lib.cough_featurizer_destroy.argtypes = [vp]
+        lib.cough_featurizer_destroy.restype = None
+        lib.cough_featurizer_num_features.argtypes = [vp]
+        lib.cough_featurizer_num_frames.argtypes = [vp]
+        lib.cough_featurize.argtypes = [vp, vp, ll, vp, i, i, vp]
+        lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
+        lib.cough_resnet_destroy.argtypes = [vp]
+        lib.cough_resnet_destroy.restype = None
+        lib.cough_resnet_workspace_bytes.argtypes = [vp, i, i, i]
+        lib.cough_resnet_workspace_bytes.restype = C.c_size_t
+        lib.cough_resnet_forward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.cough_resnet_read_activation.argtypes = [vp, vp, i, i, i, i, vp, vp]
+        lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
+        lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]
+        if lib.cough_amd_abi_version() != 1:
+            raise RuntimeError("libcough_amd.so ABI version mismatch; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    """Map a C status to the reference's exception convention
+    (ValueError for argument/config errors, as src/model.py:313-314; RuntimeError otherwise)."""
+    if status == OK:
+        return
+    msg = load().cough_amd_last_error().decode("utf-8", "replace")
+    if status in (EINVAL, EUNSUPPORTED):
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (status {status})")
+
+
+def fptr(t):
+    """Host float32 pointer of a contiguous CPU torch tensor / numpy array (caller keeps it alive)."""
+    import numpy as np
+    if hasattr(t, "data_ptr"):
+        return C.cast(t.data_ptr(), _FP)
+    assert isinstance(t, np.ndarray) and t.dtype == np.float32 and t.flags["C_CONTIGUOUS"]
+    return t.ctypes.data_as(_FP)

@@ -1,0 +1,584 @@
+// K2-K5 -- CoughDetectorResidual forward for gfx950 (eval mode).
+//
+// Replaces /root/reference/src/model.py:253-259 (forward), :285-293 (ResidualBlock.forward),
+// :261-265 (predict).  BatchNorm (running stats) is folded into the conv weights at create time;
+// Dropout is the identity in eval mode.
+//
+//   K2 stem   conv7x7 s2 p3 (1->32) + BN + ReLU + maxpool2: implicit GEMM on v_mfma_f32_32x32x2_f32
+//             (exact f32; K = 49).  GEMM rows are ordered (pool window, dy, dx) so that the 2x2 max
+//             is a max over 4 accumulator registers of one lane -- the 32x45x51 conv output is
+//             never materialised.
+//   K3/K4     residual blocks as implicit GEMMs over NHWC activations:
+//               h   = ReLU(conv3x3 s2 (x) * bn1)                      K = 9*Cin
+//               out = ReLU(conv3x3 s1 (h) * bn2 + conv1x1 s2 (x) * bn_skip)   K = 9*Cout + Cin
+//             the projection skip is appended to the K loop of conv2, so skip / add / ReLU cost no
+//             extra pass.  FP32: v_mfma_f32_32x32x2_f32; BF16: v_mfma_f32_32x32x16_bf16, f32 accumulate.
+//   K5 tail   global mean over HxW -> Linear(128,2) -> optional softmax / argmax.
+//
+// A third "direct" path (plain f32 FMA loops, one thread per output) exists only as an on-device
+// cross-check of the MFMA index math; the Python surface never selects it.
+#include <hip/hip_bf16.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+#define COUGH_DTYPE_DIRECT 2
+
+namespace cough {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef uint16_t bf16_t;   // storage type of bf16 activations / weights
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+inline bf16_t f2bf_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return bf16_t(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+
+struct Shapes {
+    int H, W;          // feature image
+    int P1h, P1w;      // after stem + maxpool
+    int B0h, B0w;      // after block 0
+    int B1h, B1w;      // after block 1
+};
+inline Shapes make_shapes(int H, int W) {
+    Shapes s;
+    s.H = H; s.W = W;
+    const int c1h = (H + 6 - 7) / 2 + 1, c1w = (W + 6 - 7) / 2 + 1;
+    s.P1h = c1h / 2; s.P1w = c1w / 2;
+    s.B0h = (s.P1h + 2 - 3) / 2 + 1; s.B0w = (s.P1w + 2 - 3) / 2 + 1;
+    s.B1h = (s.B0h + 2 - 3) / 2 + 1; s.B1w = (s.B0w + 2 - 3) / 2 + 1;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------ K2 stem
+constexpr int STEM_K = 49, STEM_KS = 25, STEM_N = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w,
+                                                        long long n_pool /* B*P1h*P1w */,
+                                                        const float* __restrict__ wk /* [50][32] */,
+                                                        const float* __restrict__ bias, T* __restrict__ out) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const long long n_tiles = (n_pool + 7) / 8;
+    const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    float bw[STEM_KS];
+#pragma unroll
+    for (int ks = 0; ks < STEM_KS; ++ks) bw[ks] = wk[(2 * ks + h) * STEM_N + r];
+    const float bn = bias[r];
+    const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
+    const int per_clip = P1h * P1w;
+    for (long long tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const long long P = tile * 8 + q;
+        const bool rowok = P < n_pool;
+        const long long Pc = rowok ? P : 0;
+        const int b = int(Pc / per_clip), rem = int(Pc - (long long)b * per_clip);
+        const int ph = rem / P1w, pw = rem - ph * P1w;
+        const int ih0 = 2 * (2 * ph + dy) - 3, iw0 = 2 * (2 * pw + dx) - 3;
+        const float* src = feat + (long long)b * H * W;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < STEM_KS; ++ks) {
+            const int k0 = 2 * ks, k1 = 2 * ks + 1;                       // compile-time taps of the two halves
+            const int kh = h ? (k1 < STEM_K ? k1 / 7 : 0) : k0 / 7;
+            const int kw = h ? (k1 < STEM_K ? k1 % 7 : 0) : k0 % 7;
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            float a = 0.f;
+            if (rowok && ih >= 0 && ih < H && iw >= 0 && iw < W) a = src[ih * W + iw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[ks], acc, 0, 0, 0);
+        }
+        // C layout: col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*h -> pool window 2*(reg>>2)+h
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long long Po = tile * 8 + 2 * g + h;
+            float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bn;
+            v = fmaxf(v, 0.f);
+            if (Po < n_pool) out[Po * STEM_N + r] = from_f32<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void stem_direct_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w, long long n_pool,
+                                   const float* __restrict__ wk, const float* __restrict__ bias, T* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pool * STEM_N) return;
+    const int n = int(idx % STEM_N);
+    const long long P = idx / STEM_N;
+    const int per_clip = P1h * P1w;
+    const int b = int(P / per_clip), rem = int(P - (long long)b * per_clip), ph = rem / P1w, pw = rem - ph * P1w;
+    const float* src = feat + (long long)b * H * W;
+    float best = -INFINITY;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ih0 = 2 * (2 * ph + dy) - 3, iw0 = 2 * (2 * pw + dx) - 3;
+            float acc = 0.f;
+            for (int k = 0; k < STEM_K; ++k) {
+                const int ih = ih0 + k / 7, iw = iw0 + k % 7;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) acc = fmaf(src[ih * W + iw], wk[k * STEM_N + n], acc);
+            }
+            best = fmaxf(best, acc);
+        }
+    out[idx] = from_f32<T>(fmaxf(best + bias[n], 0.f));
+}
+
+// ------------------------------------------------------------------------------------ K3/K4 convs
+template <typename T>
+struct ConvArgs {
+    const T* in;      // NHWC [B][H][W][C]
+    int H, W, C, KH, KW, stride, pad;
+    const T* in2;     // optional fused 1x1 projection input NHWC [B][H2][W2][C2] (C2 = 0: none)
+    int H2, W2, C2, stride2;
+    const T* wp;      // [N][Ktot], k = ((kh*KW + kw)*C + c), then C2 skip channels
+    const float* bias;
+    T* out;           // NHWC [B][OH][OW][N]
+    int OH, OW, N, Ktot;
+    long long M;      // B*OH*OW
+};
+
+// K chunking of the implicit GEMM (A and B use the same channel <-> k-slot map):
+//   f32 : 8 channels per chunk, four v_mfma_f32_32x32x2_f32; k-slot h of step e <-> channel 4h+e
+//   bf16: 16 channels per chunk, one v_mfma_f32_32x32x16_bf16; lane half h holds channels 8h..8h+7
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const long long m0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
+    if (m0 >= a.M) return;
+    const long long m = m0 + r;
+    const bool rowok = m < a.M;
+    const long long mc = rowok ? m : 0;
+    const int per = a.OH * a.OW;
+    const int b = int(mc / per), rem = int(mc - (long long)b * per), oh = rem / a.OW, ow = rem - oh * a.OW;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16{0};
+
+    const T* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.wp + (long long)(nt * 32 + r) * a.Ktot;
+
+    int kbase = 0;
+    for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            const bool ok = rowok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const T* ap = a.in + (((long long)b * a.H + (ok ? ih : 0)) * a.W + (ok ? iw : 0)) * a.C;
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll 2
+                for (int c0 = 0; c0 < a.C; c0 += 8) {
+                    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) av = *reinterpret_cast<const float4*>(ap + c0 + 4 * h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 bv = *reinterpret_cast<const float4*>(wrow[nt] + kbase + c0 + 4 * h);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int c0 = 0; c0 < a.C; c0 += 16) {
+                    bf16x8 av = {0};
+                    if (ok) av = *reinterpret_cast<const bf16x8*>(ap + c0 + 8 * h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wrow[nt] + kbase + c0 + 8 * h);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            kbase += a.C;
+        }
+    if (a.C2 > 0) {   // fused 1x1 stride-s projection of the block input (model.py:280-283)
+        const T* ap = a.in2 + (((long long)b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.C2;
+        if constexpr (sizeof(T) == 4) {
+            for (int c0 = 0; c0 < a.C2; c0 += 8) {
+                float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok) av = *reinterpret_cast<const float4*>(ap + c0 + 4 * h);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 bv = *reinterpret_cast<const float4*>(wrow[nt] + kbase + c0 + 4 * h);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                }
+            }
+        } else {
+            for (int c0 = 0; c0 < a.C2; c0 += 16) {
+                bf16x8 av = {0};
+                if (rowok) av = *reinterpret_cast<const bf16x8*>(ap + c0 + 8 * h);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wrow[nt] + kbase + c0 + 8 * h);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: + folded bias, ReLU, NHWC store (lane = channel -> 32 consecutive channels per row)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + r;
+        const float bn = a.bias[n];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long long mo = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (mo < a.M) a.out[mo * a.N + n] = from_f32<T>(fmaxf(acc[nt][reg] + bn, 0.f));
+        }
+    }
+}
+
+template <typename T>
+__global__ void conv_direct_kernel(ConvArgs<T> a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.N) return;
+    const int n = int(idx % a.N);
+    const long long m = idx / a.N;
+    const int per = a.OH * a.OW;
+    const int b = int(m / per), rem = int(m - (long long)b * per), oh = rem / a.OW, ow = rem - oh * a.OW;
+    const T* w = a.wp + (long long)n * a.Ktot;
+    float acc = 0.f;
+    int kbase = 0;
+    for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+                const T* ap = a.in + (((long long)b * a.H + ih) * a.W + iw) * a.C;
+                for (int c = 0; c < a.C; ++c) acc = fmaf(to_f32<T>(ap[c]), to_f32<T>(w[kbase + c]), acc);
+            }
+            kbase += a.C;
+        }
+    if (a.C2 > 0) {
+        const T* ap = a.in2 + (((long long)b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.C2;
+        for (int c = 0; c < a.C2; ++c) acc = fmaf(to_f32<T>(ap[c]), to_f32<T>(w[kbase + c]), acc);
+    }
+    a.out[idx] = from_f32<T>(fmaxf(acc + a.bias[n], 0.f));
+}
+
+// ------------------------------------------------------------------------------------ K5 tail
+template <typename T>
+__global__ __launch_bounds__(128) void tail_kernel(const T* __restrict__ a3, int HW, const float* __restrict__ fcw,
+                                                   const float* __restrict__ fcb, float* __restrict__ logits,
+                                                   float* __restrict__ probs, int* __restrict__ preds) {
+    __shared__ float red[2][2];
+    const int c = threadIdx.x;   // 128 channels
+    const long long b = blockIdx.x;
+    const T* p = a3 + b * (long long)HW * 128 + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += to_f32<T>(p[(long long)i * 128]);
+    const float mean = s / float(HW);
+    float l0 = wave_sum(mean * fcw[c]), l1 = wave_sum(mean * fcw[128 + c]);
+    if ((c & 63) == 0) { red[c >> 6][0] = l0; red[c >> 6][1] = l1; }
+    __syncthreads();
+    if (c == 0) {
+        l0 = red[0][0] + red[1][0] + fcb[0];
+        l1 = red[0][1] + red[1][1] + fcb[1];
+        logits[b * 2] = l0;
+        logits[b * 2 + 1] = l1;
+        if (probs) {
+            const float mx = fmaxf(l0, l1), e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.0f / (e0 + e1);
+            probs[b * 2] = e0 * inv;
+            probs[b * 2 + 1] = e1 * inv;
+        }
+        if (preds) preds[b] = (l1 > l0) ? 1 : 0;   // argmax returns the first maximal index on ties
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int hw = int(idx % HW);
+    const long long t = idx / HW;
+    const int c = int(t % C);
+    const long long b = t / C;
+    out[idx] = to_f32<T>(in[(b * HW + hw) * C + c]);
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct FoldedConv {
+    std::vector<float> w;   // [N][K] with k = (kh*KW + kw)*C + c
+    std::vector<float> b;   // [N]
+    int N, C, KH, KW;
+};
+
+FoldedConv fold(const cough_conv_bn& p, int N, int C, int KH, int KW, float eps) {
+    FoldedConv f;
+    f.N = N; f.C = C; f.KH = KH; f.KW = KW;
+    const int K = KH * KW * C;
+    f.w.resize(size_t(N) * K);
+    f.b.resize(N);
+    for (int n = 0; n < N; ++n) {
+        const double scale = double(p.bn_w[n]) / std::sqrt(double(p.bn_var[n]) + double(eps));
+        f.b[n] = float((double(p.b[n]) - double(p.bn_mean[n])) * scale + double(p.bn_b[n]));
+        for (int c = 0; c < C; ++c)
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < KW; ++kw)
+                    f.w[size_t(n) * K + (kh * KW + kw) * C + c] =
+                        float(double(p.w[((size_t(n) * C + c) * KH + kh) * KW + kw]) * scale);
+    }
+    return f;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+}  // namespace
+}  // namespace cough
+
+struct cough_resnet {
+    int dtype;
+    size_t esize;          // activation element size
+    float* d_stem_w;       // [50][32]
+    float* d_stem_b;       // [32]
+    void* d_w[4];          // packed [N][Ktot]: b0.conv1, b0.conv2+skip, b1.conv1, b1.conv2+skip
+    float* d_b[4];
+    int ktot[4];
+    float* d_fcw;          // [2][128]
+    float* d_fcb;
+};
+
+namespace cough {
+namespace {
+
+template <typename T>
+int upload(void** dst, const std::vector<T>& v) {
+    COUGH_HIP_CHECK(hipMalloc(dst, v.size() * sizeof(T)));
+    COUGH_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return COUGH_OK;
+}
+
+int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const FoldedConv* skip) {
+    const int N = main.N, Km = main.KH * main.KW * main.C, Ks = skip ? skip->C : 0, K = Km + Ks;
+    std::vector<float> w(size_t(N) * K), b(N);
+    for (int n = 0; n < N; ++n) {
+        std::memcpy(&w[size_t(n) * K], &main.w[size_t(n) * Km], Km * sizeof(float));
+        if (skip) std::memcpy(&w[size_t(n) * K + Km], &skip->w[size_t(n) * Ks], Ks * sizeof(float));
+        b[n] = main.b[n] + (skip ? skip->b[n] : 0.f);
+    }
+    m->ktot[slot] = K;
+    if (m->esize == 4) {
+        if (int e = upload(&m->d_w[slot], w)) return e;
+    } else {
+        std::vector<bf16_t> wb(w.size());
+        for (size_t i = 0; i < w.size(); ++i) wb[i] = f2bf_host(w[i]);
+        if (int e = upload(&m->d_w[slot], wb)) return e;
+    }
+    return upload(reinterpret_cast<void**>(&m->d_b[slot]), b);
+}
+
+struct Workspace {
+    char *a1, *h0, *a2, *h1, *a3;
+    size_t total;
+};
+Workspace carve(const cough_resnet* m, char* base, int n, const Shapes& s) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t elems) { char* p = base + off; off += align256(elems * m->esize); return p; };
+    w.a1 = take(size_t(n) * s.P1h * s.P1w * 32);
+    w.h0 = take(size_t(n) * s.B0h * s.B0w * 64);
+    w.a2 = take(size_t(n) * s.B0h * s.B0w * 64);
+    w.h1 = take(size_t(n) * s.B1h * s.B1w * 128);
+    w.a3 = take(size_t(n) * s.B1h * s.B1w * 128);
+    w.total = off;
+    return w;
+}
+
+template <typename T>
+int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
+    if (a.M == 0) return COUGH_OK;
+    if (m->dtype == COUGH_DTYPE_DIRECT) {
+        const long long total = a.M * a.N;
+        hipLaunchKernelGGL(conv_direct_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        const long long tiles = (a.M + 31) / 32;
+        const dim3 grid((unsigned)((tiles + 3) / 4));
+        if (a.N == 64) hipLaunchKernelGGL((conv_mfma_kernel<T, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_mfma_kernel<T, 4>), grid, dim3(256), 0, st, a);
+    }
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+template <typename T>
+int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes& s, float* d_logits, float* d_probs,
+                 int* d_preds, char* ws, hipStream_t st) {
+    const Workspace w = carve(m, ws, n, s);
+    const long long n_pool = (long long)n * s.P1h * s.P1w;
+    if (m->dtype == COUGH_DTYPE_DIRECT) {
+        hipLaunchKernelGGL(stem_direct_kernel<T>, dim3((unsigned)((n_pool * 32 + 255) / 256)), dim3(256), 0, st, d_feat,
+                           s.H, s.W, s.P1h, s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
+    } else {
+        const long long tiles = (n_pool + 7) / 8;
+        long long blocks = (tiles + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;   // grid-stride over tiles: weights stay in registers
+        hipLaunchKernelGGL(stem_mfma_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, d_feat, s.H, s.W, s.P1h,
+                           s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
+    }
+    COUGH_HIP_CHECK(hipGetLastError());
+
+    struct Blk { char *x, *h, *out; int xh, xw, oh, ow, cin, cout, s1, s2; };
+    const Blk blk[2] = {{w.a1, w.h0, w.a2, s.P1h, s.P1w, s.B0h, s.B0w, 32, 64, 0, 1},
+                        {w.a2, w.h1, w.a3, s.B0h, s.B0w, s.B1h, s.B1w, 64, 128, 2, 3}};
+    for (int i = 0; i < 2; ++i) {
+        const Blk& k = blk[i];
+        ConvArgs<T> c1{};
+        c1.in = reinterpret_cast<const T*>(k.x); c1.H = k.xh; c1.W = k.xw; c1.C = k.cin;
+        c1.KH = 3; c1.KW = 3; c1.stride = 2; c1.pad = 1;
+        c1.in2 = nullptr; c1.C2 = 0; c1.H2 = c1.W2 = 0; c1.stride2 = 1;
+        c1.wp = reinterpret_cast<const T*>(m->d_w[k.s1]); c1.bias = m->d_b[k.s1];
+        c1.out = reinterpret_cast<T*>(k.h); c1.OH = k.oh; c1.OW = k.ow; c1.N = k.cout; c1.Ktot = m->ktot[k.s1];
+        c1.M = (long long)n * k.oh * k.ow;
+        if (int e = launch_conv<T>(m, c1, st)) return e;
+        ConvArgs<T> c2{};
+        c2.in = reinterpret_cast<const T*>(k.h); c2.H = k.oh; c2.W = k.ow; c2.C = k.cout;
+        c2.KH = 3; c2.KW = 3; c2.stride = 1; c2.pad = 1;
+        c2.in2 = reinterpret_cast<const T*>(k.x); c2.H2 = k.xh; c2.W2 = k.xw; c2.C2 = k.cin; c2.stride2 = 2;
+        c2.wp = reinterpret_cast<const T*>(m->d_w[k.s2]); c2.bias = m->d_b[k.s2];
+        c2.out = reinterpret_cast<T*>(k.out); c2.OH = k.oh; c2.OW = k.ow; c2.N = k.cout; c2.Ktot = m->ktot[k.s2];
+        c2.M = (long long)n * k.oh * k.ow;
+        if (int e = launch_conv<T>(m, c2, st)) return e;
+    }
+    hipLaunchKernelGGL(tail_kernel<T>, dim3(n), dim3(128), 0, st, reinterpret_cast<const T*>(w.a3), s.B1h * s.B1w,
+                       m->d_fcw, m->d_fcb, d_logits, d_probs, d_preds);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+}  // namespace
+}  // namespace cough
+
+extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype) {
+    using namespace cough;
+    COUGH_REQUIRE(out && w, COUGH_EINVAL, "cough_resnet_create: NULL argument");
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_DIRECT, COUGH_EINVAL,
+                  "cough_resnet_create: unknown dtype %d", dtype);
+    const cough_conv_bn* all[7] = {&w->stem, &w->block[0].conv1, &w->block[0].conv2, &w->block[0].skip,
+                                   &w->block[1].conv1, &w->block[1].conv2, &w->block[1].skip};
+    for (const cough_conv_bn* p : all)
+        COUGH_REQUIRE(p->w && p->b && p->bn_w && p->bn_b && p->bn_mean && p->bn_var, COUGH_EINVAL,
+                      "cough_resnet_create: NULL weight pointer");
+    COUGH_REQUIRE(w->fc_w && w->fc_b, COUGH_EINVAL, "cough_resnet_create: NULL fc pointer");
+
+    cough_resnet* m = new cough_resnet();
+    std::memset(m, 0, sizeof(*m));
+    m->dtype = dtype;
+    m->esize = (dtype == COUGH_DTYPE_BF16) ? 2 : 4;
+    const float eps = w->bn_eps;
+
+    int err = COUGH_OK;
+    {   // stem: [50][32], k = kh*7 + kw, row 49 = 0 (K padded to the MFMA k-step)
+        const FoldedConv f = fold(w->stem, 32, 1, 7, 7, eps);
+        std::vector<float> wk(size_t(50) * 32, 0.f);
+        for (int n = 0; n < 32; ++n)
+            for (int k = 0; k < 49; ++k) wk[size_t(k) * 32 + n] = f.w[size_t(n) * 49 + k];
+        err = upload(reinterpret_cast<void**>(&m->d_stem_w), wk);
+        if (!err) err = upload(reinterpret_cast<void**>(&m->d_stem_b), f.b);
+    }
+    const int cin[2] = {32, 64}, cout[2] = {64, 128};
+    for (int i = 0; i < 2 && !err; ++i) {
+        const FoldedConv c1 = fold(w->block[i].conv1, cout[i], cin[i], 3, 3, eps);
+        const FoldedConv c2 = fold(w->block[i].conv2, cout[i], cout[i], 3, 3, eps);
+        const FoldedConv sk = fold(w->block[i].skip, cout[i], cin[i], 1, 1, eps);
+        err = upload_packed(m, 2 * i, c1, nullptr);
+        if (!err) err = upload_packed(m, 2 * i + 1, c2, &sk);
+    }
+    if (!err) {
+        std::vector<float> fw(w->fc_w, w->fc_w + 256), fb(w->fc_b, w->fc_b + 2);
+        err = upload(reinterpret_cast<void**>(&m->d_fcw), fw);
+        if (!err) err = upload(reinterpret_cast<void**>(&m->d_fcb), fb);
+    }
+    if (err) {
+        cough_resnet_destroy(m);
+        return err;
+    }
+    *out = m;
+    return COUGH_OK;
+}
+
+extern "C" void cough_resnet_destroy(cough_resnet* m) {
+    if (!m) return;
+    (void)hipFree(m->d_stem_w);
+    (void)hipFree(m->d_stem_b);
+    for (int i = 0; i < 4; ++i) {
+        (void)hipFree(m->d_w[i]);
+        (void)hipFree(m->d_b[i]);
+    }
+    (void)hipFree(m->d_fcw);
+    (void)hipFree(m->d_fcb);
+    delete m;
+}
+
+extern "C" size_t cough_resnet_workspace_bytes(const cough_resnet* m, int n_clips, int height, int width) {
+    using namespace cough;
+    if (!m || n_clips < 0 || height < 1 || width < 1) return 0;
+    return carve(m, nullptr, n_clips, make_shapes(height, width)).total;
+}
+
+extern "C" int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips, int height, int width,
+                                    float* d_logits, float* d_probs, int* d_preds, void* d_workspace,
+                                    size_t workspace_bytes, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(m && d_feat && d_logits && d_workspace, COUGH_EINVAL, "cough_resnet_forward: NULL argument");
+    COUGH_REQUIRE(n_clips >= 0 && height >= 1 && width >= 1, COUGH_EINVAL, "cough_resnet_forward: bad shape");
+    const Shapes s = make_shapes(height, width);
+    COUGH_REQUIRE(s.B1h >= 1 && s.B1w >= 1 && s.P1h >= 1 && s.P1w >= 1, COUGH_EINVAL,
+                  "cough_resnet_forward: input %dx%d too small for the network", height, width);
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL,
+                  "cough_resnet_forward: workspace must be 256-byte aligned");
+    COUGH_REQUIRE(workspace_bytes >= cough_resnet_workspace_bytes(m, n_clips, height, width), COUGH_EWORKSPACE,
+                  "cough_resnet_forward: workspace too small");
+    if (n_clips == 0) return COUGH_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(d_workspace);
+    if (m->esize == 4) return forward_impl<float>(m, d_feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
+    return forward_impl<bf16_t>(m, d_feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
+}
+
+extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips, int height,
+                                            int width, int which, float* d_out, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(m && d_workspace && d_out, COUGH_EINVAL, "cough_resnet_read_activation: NULL argument");
+    COUGH_REQUIRE(which >= 1 && which <= 3, COUGH_EINVAL, "cough_resnet_read_activation: which must be 1..3");
+    const Shapes s = make_shapes(height, width);
+    const Workspace w = carve(m, const_cast<char*>(static_cast<const char*>(d_workspace)), n_clips, s);
+    const char* src = which == 1 ? w.a1 : which == 2 ? w.a2 : w.a3;
+    const int C = which == 1 ? 32 : which == 2 ? 64 : 128;
+    const int HW = which == 1 ? s.P1h * s.P1w : which == 2 ? s.B0h * s.B0w : s.B1h * s.B1w;
+    const long long total = (long long)n_clips * C * HW;
+    if (total == 0) return COUGH_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (m->esize == 4)
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(src),
+                           d_out, C, HW, total);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<bf16_t>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const bf16_t*>(src), d_out, C, HW, total);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}

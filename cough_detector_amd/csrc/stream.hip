@@ -1,0 +1,58 @@
+// K6 -- multi-stream ring buffers on device: the batched counterpart of the per-stream FIFO in
+// RealtimePreprocessor.add_audio (/root/reference/src/preprocessing.py:597-610: append chunk, cut
+// windows of window_samples, drop hop_samples).  Positions are absolute sample counters kept by the
+// host; ring index = pos % ring_len.  Pure byte movement, HBM/L2-bound.
+#include "common.h"
+
+namespace cough {
+namespace {
+
+__global__ void ring_write_kernel(float* __restrict__ rings, int ring_len, const float* __restrict__ chunks,
+                                  int chunk_len, const int* __restrict__ ids, const long long* __restrict__ wpos) {
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk_len) return;
+    const long long p = (wpos[c] + i) % ring_len;
+    rings[(long long)ids[c] * ring_len + p] = chunks[(long long)c * chunk_len + i];
+}
+
+__global__ void window_gather_kernel(const float* __restrict__ rings, int ring_len, const int* __restrict__ ids,
+                                     const long long* __restrict__ spos, int window_len, float* __restrict__ out) {
+    const int w = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= window_len) return;
+    const long long p = (spos[w] + i) % ring_len;
+    out[(long long)w * window_len + i] = rings[(long long)ids[w] * ring_len + p];
+}
+
+}  // namespace
+}  // namespace cough
+
+extern "C" int cough_ring_write(float* d_rings, int ring_len, const float* d_chunks, int chunk_len,
+                                const int* d_stream_ids, const long long* d_write_pos, int n_chunks, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_rings && d_chunks && d_stream_ids && d_write_pos, COUGH_EINVAL, "cough_ring_write: NULL argument");
+    COUGH_REQUIRE(ring_len > 0 && chunk_len >= 0 && chunk_len <= ring_len && n_chunks >= 0 && n_chunks <= 65535,
+                  COUGH_EINVAL, "cough_ring_write: need 0 <= chunk_len <= ring_len, 0 <= n_chunks <= 65535");
+    if (n_chunks == 0 || chunk_len == 0) return COUGH_OK;
+    hipLaunchKernelGGL(ring_write_kernel, dim3((chunk_len + 255) / 256, n_chunks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_rings, ring_len, d_chunks, chunk_len, d_stream_ids,
+                       d_write_pos);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+extern "C" int cough_window_gather(const float* d_rings, int ring_len, const int* d_stream_ids,
+                                   const long long* d_start_pos, int n_windows, int window_len, float* d_out,
+                                   void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_rings && d_stream_ids && d_start_pos && d_out, COUGH_EINVAL, "cough_window_gather: NULL argument");
+    COUGH_REQUIRE(ring_len > 0 && window_len > 0 && window_len <= ring_len && n_windows >= 0 && n_windows <= 65535,
+                  COUGH_EINVAL, "cough_window_gather: need 0 < window_len <= ring_len, 0 <= n_windows <= 65535");
+    if (n_windows == 0) return COUGH_OK;
+    hipLaunchKernelGGL(window_gather_kernel, dim3((window_len + 255) / 256, n_windows), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_rings, ring_len, d_stream_ids, d_start_pos, window_len,
+                       d_out);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}

@@ -1,0 +1,183 @@
+"""Sliding-window detection engine with the reference's call surface.
+
+Mirrors ``/root/reference/src/inference.py``: ``CoughDetectorInference`` (:39-247: checkpoint +
+config contract :119-163, ``predict`` :165-189, ``process_audio_chunk`` :191-241, ``reset``
+:243-247) and the CLI of ``main`` (:454-503).  Featurisation and the classifier run on the MI355X
+(``preprocessing.RealtimePreprocessor`` / ``model.CoughDetectorResidual``); every window a chunk
+completes goes through ONE featurise launch and ONE classifier forward.  The smoothing / debounce
+state machine stays on the host and takes an injectable clock (the reference reads
+``datetime.now()``, :226,233), so runs are reproducible.  Microphone back-ends (:250-451) are
+hardware I/O and not part of this path; ``main`` reads a synthetic or ``.npy`` stream instead.
+"""
+from __future__ import annotations
+
+import argparse
+import time
+from collections import deque
+from datetime import datetime
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from .model import create_model
+from .preprocessing import RealtimePreprocessor
+
+
+def num_features_from_config(config: dict) -> int:
+    """Image height implied by a checkpoint config (inference.py:128-143)."""
+    n = config.get("n_mels", 64)
+    if config.get("use_mfcc", True):
+        n += 2 * config.get("n_mfcc", 13)
+        if config.get("use_delta_delta", True):
+            n += config.get("n_mfcc", 13)
+    if config.get("use_spectral_contrast", True):
+        n += config.get("n_contrast_bands", 6) + 1
+    return n
+
+
+class CoughDetectorInference:
+    def __init__(self, model_path: str, device: str = "auto", confidence_threshold: float = 0.5,
+                 smoothing_window: int = 3, debounce_seconds: float = 0.5, verbose: bool = True,
+                 clock: Optional[Callable[[], float]] = None, compute_dtype: str = "fp32"):
+        self.verbose = verbose
+        self.confidence_threshold = confidence_threshold
+        self.debounce_seconds = debounce_seconds
+        self.compute_dtype = compute_dtype
+        if device == "auto":
+            device = "cuda"
+        if str(device).startswith("cpu") or str(device) == "mps":
+            raise ValueError(f"device={device!r}: this engine runs on the MI355X only (use 'auto' or 'cuda')")
+        if not torch.cuda.is_available():
+            raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.verbose:
+            print(f"Using device: {self.device}")
+        self._load_model(model_path)
+        cfg = self.config
+        self.preprocessor = RealtimePreprocessor(
+            sample_rate=cfg.get("sample_rate", 16000), n_mels=cfg.get("n_mels", 64), n_fft=cfg.get("n_fft", 512),
+            hop_length=cfg.get("hop_length", 160), win_length=cfg.get("win_length", 400),
+            f_min=cfg.get("f_min", 100.0), f_max=cfg.get("f_max", 4000.0),
+            window_duration=cfg.get("segment_duration", 1.0), hop_duration=0.25,
+            n_mfcc=cfg.get("n_mfcc", 13), use_mfcc=cfg.get("use_mfcc", True), use_pcen=cfg.get("use_pcen", True),
+            use_pre_emphasis=cfg.get("use_pre_emphasis", True),
+            pre_emphasis_coef=cfg.get("pre_emphasis_coef", 0.97),
+            use_delta_delta=cfg.get("use_delta_delta", True),
+            use_spectral_contrast=cfg.get("use_spectral_contrast", True),
+            n_contrast_bands=cfg.get("n_contrast_bands", 6), device="cuda")
+        self.prediction_history = deque(maxlen=smoothing_window)
+        self.last_detection_time = 0
+        self.on_cough_detected: Optional[Callable[[datetime, float], None]] = None
+        self._clock = clock or (lambda: datetime.now().timestamp())
+        self.window_probs = []      # every per-window cough probability seen (diagnostics / parity tests)
+
+    def _load_model(self, model_path):
+        if self.verbose:
+            print(f"Loading model from {model_path}")
+        checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+        self.config = checkpoint.get("config", {})
+        model_type = self.config.get("model_type", "small")
+        self.model = create_model(model_type=model_type, n_mels=num_features_from_config(self.config),
+                                  num_classes=2, in_channels=1, compute_dtype=self.compute_dtype)
+        self.model.load_state_dict(checkpoint["model_state_dict"])
+        self.model.to(self.device)
+        self.model.eval()
+        if self.verbose:
+            print(f"Model loaded: {model_type}")
+            metrics = checkpoint.get("metrics", {})
+            if metrics:
+                print(f"  Validation F1: {metrics.get('f1', float('nan')):.4f}")
+
+    @torch.no_grad()
+    def predict_batch(self, spectrograms: torch.Tensor) -> torch.Tensor:
+        """(n, F, T) or (n, 1, F, T) on any device -> (n,) cough probabilities on the host (one sync)."""
+        if spectrograms.dim() == 3:
+            spectrograms = spectrograms.unsqueeze(1)
+        _, probs = self.model.predict(spectrograms.to(self.device))
+        return probs[:, 1].to("cpu")
+
+    @torch.no_grad()
+    def predict(self, spectrogram: torch.Tensor) -> tuple:
+        """(1, F, T) or (B, 1, F, T) -> (is_cough, confidence) of element 0, as the reference."""
+        if spectrogram.dim() == 3:
+            spectrogram = spectrogram.unsqueeze(0)
+        cough_prob = self.predict_batch(spectrogram)[0].item()
+        return cough_prob > 0.5, cough_prob
+
+    def process_audio_chunk(self, audio_chunk) -> Optional[tuple]:
+        if isinstance(audio_chunk, np.ndarray):
+            audio_chunk = torch.from_numpy(audio_chunk.astype(np.float32))
+        if audio_chunk.dim() == 1:
+            audio_chunk = audio_chunk.unsqueeze(0)
+        if audio_chunk.shape[0] > 1:
+            audio_chunk = audio_chunk.mean(dim=0, keepdim=True)
+        windows = self.preprocessor.take_windows(audio_chunk)
+        if windows is None:
+            return None
+        feats = self.preprocessor.featurize_batch(windows, normalize=True)       # stays on the GPU
+        probs = self.predict_batch(feats).tolist()
+        for confidence in probs:
+            self.window_probs.append(confidence)
+            self.prediction_history.append(confidence)
+            smoothed = float(np.mean(self.prediction_history))
+            now = self._clock()
+            if smoothed >= self.confidence_threshold and now - self.last_detection_time >= self.debounce_seconds:
+                self.last_detection_time = now
+                timestamp = datetime.fromtimestamp(now)
+                if self.on_cough_detected:
+                    self.on_cough_detected(timestamp, smoothed)
+                return timestamp, smoothed      # later windows of this chunk are dropped, as inference.py:239
+        return None
+
+    def reset(self):
+        self.preprocessor.reset()
+        self.prediction_history.clear()
+        self.last_detection_time = 0
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Real-time cough detection (MI355X path)")
+    parser.add_argument("--model", type=str, required=True, help="Path to trained model checkpoint")
+    parser.add_argument("--threshold", type=float, default=0.7, help="Confidence threshold for detection (0-1)")
+    parser.add_argument("--smoothing", type=int, default=3, help="Number of predictions to average")
+    parser.add_argument("--debounce", type=float, default=0.5, help="Minimum seconds between detections")
+    parser.add_argument("--device", type=str, default="auto", help="Compute device (auto, cuda)")
+    parser.add_argument("--audio-device", type=int, default=None, help="(accepted for compatibility; unused)")
+    parser.add_argument("--backend", type=str, default="auto", choices=["auto", "sounddevice", "pyaudio"],
+                        help="(accepted for compatibility; microphone capture is not part of this build)")
+    parser.add_argument("--list-devices", action="store_true", help="List available audio devices and exit")
+    parser.add_argument("--quiet", action="store_true", help="Suppress verbose output")
+    parser.add_argument("--input", type=str, default=None,
+                        help=".npy file with a 16 kHz mono float32 stream (default: a synthetic stream)")
+    parser.add_argument("--seconds", type=float, default=10.0, help="Length of the synthetic stream")
+    args = parser.parse_args(argv)
+    if args.list_devices:
+        print("No audio capture back-end in this build; pass --input stream.npy or use the synthetic stream.")
+        return
+    engine = CoughDetectorInference(model_path=args.model, device=args.device, confidence_threshold=args.threshold,
+                                    smoothing_window=args.smoothing, debounce_seconds=args.debounce,
+                                    verbose=not args.quiet)
+    if args.input:
+        stream = np.load(args.input).astype(np.float32).reshape(-1)
+    else:
+        from .synth import make_stream
+        stream = make_stream(0, args.seconds)
+    sr = engine.config.get("sample_rate", 16000)
+    chunk = int(sr * 0.1)
+    t0, detections = time.time(), 0
+    sim = {"t": 0.0}
+    engine._clock = lambda: sim["t"]        # stream time, not wall time: 0.1 s per chunk
+    for i in range(0, len(stream) - chunk + 1, chunk):
+        sim["t"] = (i + chunk) / sr
+        hit = engine.process_audio_chunk(stream[i:i + chunk])
+        if hit is not None:
+            detections += 1
+            if not args.quiet:
+                print(f"[{sim['t']:7.2f}s] COUGH DETECTED (confidence: {hit[1]:.1%})")
+    if not args.quiet:
+        print(f"{len(engine.window_probs)} windows, {detections} detections, {time.time() - t0:.2f} s wall")
+
+
+if __name__ == "__main__":
+    main()

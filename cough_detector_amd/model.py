@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference classifier interface, backed by the HIP kernels K2-K5.
+
+Same names and constructor arguments as ``/root/reference/src/model.py``
+(``CoughDetectorResidual`` :210-265, ``ResidualBlock`` :268-293, ``create_model`` :296-316,
+``count_parameters`` :319-321).  The modules below are *parameter containers* with the reference's
+exact sub-module layout, so ``state_dict()`` / ``load_state_dict()`` use the reference's keys
+(``conv1.0.weight`` ... ``fc.2.bias``); ``forward`` does not run them -- it hands the tensors to
+``cough_resnet_forward`` (``csrc/resnet.hip``) through the C-ABI.  Inference (eval mode) only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class ResidualBlock(nn.Module):
+    """Parameter layout of the reference block: conv1/bn1 (3x3 s2), conv2/bn2 (3x3 s1), skip (1x1 s2 + BN)."""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
+        super().__init__()
+        if stride != 2 or in_channels == out_channels:
+            raise ValueError("ResidualBlock: the MI355X path implements the projection block (stride 2, "
+                             "in_channels != out_channels) used by CoughDetectorResidual")
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=stride, padding=1)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.skip = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, stride=stride),
+                                  nn.BatchNorm2d(out_channels))
+
+    def forward(self, x):
+        raise RuntimeError("ResidualBlock is executed inside CoughDetectorResidual.forward on the MI355X path")
+
+
+class CoughDetectorResidual(nn.Module):
+    """Residual CNN, (B, 1, F, T) float32 -> (B, 2) logits, executed by hand-written gfx950 kernels.
+
+    ``compute_dtype``: "fp32" (exact-f32 MFMA, CPU-reference numerics) or "bf16" (bf16 operands,
+    f32 accumulate; the stem stays f32).
+    """
+
+    def __init__(self, n_mels: int = 64, num_classes: int = 2, in_channels: int = 1,
+                 channels: Tuple[int, ...] = (32, 64, 128), dropout: float = 0.5, compute_dtype: str = "fp32"):
+        super().__init__()
+        if num_classes != 2 or in_channels != 1 or tuple(channels) != (32, 64, 128):
+            raise ValueError("CoughDetectorResidual: the MI355X path implements num_classes=2, in_channels=1, "
+                             "channels=(32, 64, 128)")
+        if compute_dtype not in ("fp32", "bf16", "_direct"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, channels[0], 7, stride=2, padding=3),
+                                   nn.BatchNorm2d(channels[0]), nn.ReLU(), nn.MaxPool2d(2))
+        self.res_blocks = nn.ModuleList()
+        in_ch = channels[0]
+        for out_ch in channels[1:]:
+            self.res_blocks.append(self._make_res_block(in_ch, out_ch))
+            in_ch = out_ch
+        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Sequential(nn.Flatten(), nn.Dropout(dropout), nn.Linear(channels[-1], num_classes))
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.eval()
+
+    def _make_res_block(self, in_ch: int, out_ch: int) -> nn.Module:
+        return ResidualBlock(in_ch, out_ch)
+
+    # ------------------------------------------------------------------ native handle
+    def _weights_key(self):
+        return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict().values())
+
+    def _release(self):
+        h, self._handle = self._handle, None
+        if h is not None:
+            try:
+                _lib.load().cough_resnet_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._release()
+
+    def _native(self) -> C.c_void_p:
+        key = self._weights_key()
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._release()
+        lib = _lib.load()
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+
+        def cb(conv: str, bn: str) -> _lib.ConvBN:
+            return _lib.ConvBN(_lib.fptr(sd[conv + ".weight"]), _lib.fptr(sd[conv + ".bias"]),
+                               _lib.fptr(sd[bn + ".weight"]), _lib.fptr(sd[bn + ".bias"]),
+                               _lib.fptr(sd[bn + ".running_mean"]), _lib.fptr(sd[bn + ".running_var"]))
+
+        w = _lib.ResNetWeights()
+        w.stem = cb("conv1.0", "conv1.1")
+        for i in range(2):
+            p = f"res_blocks.{i}"
+            w.block[i].conv1 = cb(p + ".conv1", p + ".bn1")
+            w.block[i].conv2 = cb(p + ".conv2", p + ".bn2")
+            w.block[i].skip = cb(p + ".skip.0", p + ".skip.1")
+        w.fc_w = _lib.fptr(sd["fc.2.weight"])
+        w.fc_b = _lib.fptr(sd["fc.2.bias"])
+        w.bn_eps = float(self.conv1[1].eps)
+        h = C.c_void_p()
+        _lib.check(lib.cough_resnet_create(C.byref(h), C.byref(w), _lib.DTYPES[self.compute_dtype]),
+                   "cough_resnet_create")
+        self._handle, self._handle_key = h, key
+        return h
+
+    # ------------------------------------------------------------------ forward
+    def _run(self, x: torch.Tensor, want_probs: bool):
+        if self.training:
+            raise RuntimeError("CoughDetectorResidual on the MI355X path is inference-only: call .eval()")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected input (B, 1, F, T), got {tuple(x.shape)}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        src_dev = x.device
+        xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        b, _, hgt, wid = xf.shape
+        lib, h = _lib.load(), self._native()
+        need = lib.cough_resnet_workspace_bytes(h, b, hgt, wid)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        logits = torch.empty((b, 2), dtype=torch.float32, device=dev)
+        probs = torch.empty((b, 2), dtype=torch.float32, device=dev) if want_probs else None
+        preds = torch.empty((b,), dtype=torch.int32, device=dev) if want_probs else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.cough_resnet_forward(h, xf.data_ptr(), b, hgt, wid, logits.data_ptr(),
+                                            probs.data_ptr() if want_probs else None,
+                                            preds.data_ptr() if want_probs else None,
+                                            self._workspace.data_ptr(), self._workspace.numel(), stream),
+                   "cough_resnet_forward")
+        self._last_shape = (b, hgt, wid)
+        if want_probs:
+            return logits.to(src_dev), probs.to(src_dev), preds.to(src_dev)
+        return logits.to(src_dev)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, want_probs=False)
+
+    def predict(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _, probs, preds = self._run(x, want_probs=True)
+        return preds.to(torch.int64), probs
+
+    def read_activation(self, which: int) -> torch.Tensor:
+        """Parity tap: activation after the stem (1), block 0 (2) or block 1 (3) of the last forward, NCHW f32."""
+        b, hgt, wid = self._last_shape
+        c = {1: 32, 2: 64, 3: 128}[which]
+        h1, w1 = ((hgt - 1) // 2 + 1) // 2, ((wid - 1) // 2 + 1) // 2
+        h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+        h3, w3 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        oh, ow = {1: (h1, w1), 2: (h2, w2), 3: (h3, w3)}[which]
+        out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=self._workspace.device)
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        _lib.check(_lib.load().cough_resnet_read_activation(self._native(), self._workspace.data_ptr(), b, hgt, wid,
+                                                            which, out.data_ptr(), stream),
+                   "cough_resnet_read_activation")
+        return out
+
+
+def create_model(model_type: str = "standard", **kwargs) -> nn.Module:
+    """Factory with the reference's signature; only the model the shipped pipeline trains
+    (``train_with_data.py:50``: "residual") exists on the MI355X path."""
+    known = ["standard", "small", "residual"]
+    if model_type not in known:
+        raise ValueError(f"Unknown model type: {model_type}. Choose from {known}")
+    if model_type != "residual":
+        raise ValueError(f"model type {model_type!r} is not implemented on the MI355X path; use 'residual'")
+    return CoughDetectorResidual(**kwargs)
+
+
+def count_parameters(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)

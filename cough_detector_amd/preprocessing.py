@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference featuriser interface, backed by the HIP kernel K1.
+
+Same names, arguments and error behaviour as ``/root/reference/src/preprocessing.py``
+(``AudioPreprocessor`` :13-550, ``RealtimePreprocessor`` :553-616, ``create_preprocessor``
+:619-632); the arithmetic of ``extract_features`` runs in ``csrc/featurize.hip`` through the
+C-ABI ``cough_featurize``.  PyTorch is used for device memory and streams only.
+
+Differences a caller can observe:
+
+* ``device`` names where results are RETURNED ("cpu" as the reference's inference engine
+  passes, or "cuda"); compute is always on the MI355X -- there is no CPU fallback.
+* ``extract_features`` additionally accepts ``(B, N)`` / ``(B, 1, N)`` batches and returns
+  ``(B, F, T)`` with the reference's per-clip reduction semantics.
+* Flag combinations the HIP path does not implement (PCEN, spectral contrast, ``use_mfcc=False``,
+  other STFT geometries, resampling) raise ``ValueError`` instead of changing the layout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib, _tables
+
+
+def _cuda_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class AudioPreprocessor:
+    """waveform -> stacked (mel | MFCC | delta [| delta-delta]) feature image on the GPU."""
+
+    def __init__(
+        self,
+        sample_rate: int = 16000,
+        n_mels: int = 64,
+        n_fft: int = 512,
+        hop_length: int = 160,
+        win_length: int = 400,
+        f_min: float = 100.0,
+        f_max: float = 4000.0,
+        segment_duration: float = 1.0,
+        n_mfcc: int = 13,
+        use_mfcc: bool = True,
+        use_pcen: bool = True,
+        use_pre_emphasis: bool = True,
+        pre_emphasis_coef: float = 0.97,
+        use_delta_delta: bool = True,
+        use_spectral_contrast: bool = True,
+        n_contrast_bands: int = 6,
+        device: str = "cpu",
+    ):
+        self.sample_rate = sample_rate
+        self.n_mels = n_mels
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.win_length = win_length
+        self.f_min = f_min
+        self.f_max = f_max
+        self.segment_duration = segment_duration
+        self.segment_samples = int(sample_rate * segment_duration)
+        self.n_mfcc = n_mfcc
+        self.use_mfcc = use_mfcc
+        self.use_pcen = use_pcen
+        self.use_pre_emphasis = use_pre_emphasis
+        self.pre_emphasis_coef = pre_emphasis_coef
+        self.use_delta_delta = use_delta_delta
+        self.use_spectral_contrast = use_spectral_contrast
+        self.n_contrast_bands = n_contrast_bands
+        self.device = device
+
+        unsupported = []
+        if use_pcen:
+            unsupported.append("use_pcen=True")
+        if use_spectral_contrast:
+            unsupported.append("use_spectral_contrast=True")
+        if not use_mfcc:
+            unsupported.append("use_mfcc=False")
+        if unsupported:
+            raise ValueError(
+                "AudioPreprocessor: " + ", ".join(unsupported) + " is not implemented on the MI355X path; the "
+                "shipped configuration (src/train.py:264-287) is use_mfcc=True, use_pcen=False, "
+                "use_spectral_contrast=False")
+        if (sample_rate, n_fft, hop_length, win_length, n_mels, n_mfcc, self.segment_samples) != \
+                (16000, 512, 160, 400, 64, 13, 16000):
+            raise ValueError("AudioPreprocessor: the MI355X path implements sample_rate=16000, n_fft=512, "
+                             "hop_length=160, win_length=400, n_mels=64, n_mfcc=13, segment_duration=1.0 only")
+
+        # host tables, built the way torchaudio builds them (preprocessing.py:94-127)
+        self._window = _tables.hann_window(win_length)
+        self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
+        self._dct = _tables.dct_matrix(n_mfcc, n_mels)
+        self._handle: Optional[C.c_void_p] = None
+
+    # ------------------------------------------------------------------ native handle
+    def _native(self) -> C.c_void_p:
+        if self._handle is None:
+            lib = _lib.load()
+            _cuda_device()
+            cfg = _lib.FeatConfig(self.sample_rate, self.n_fft, self.hop_length, self.win_length, self.n_mels,
+                                  self.n_mfcc, self.segment_samples, int(bool(self.use_pre_emphasis)),
+                                  float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)))
+            h = C.c_void_p()
+            _lib.check(lib.cough_featurizer_create(C.byref(h), C.byref(cfg), _lib.fptr(self._window),
+                                                   _lib.fptr(self._mel_fb), _lib.fptr(self._dct)),
+                       "cough_featurizer_create")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None:
+            try:
+                _lib.load().cough_featurizer_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ reference helpers (host plumbing)
+    def load_audio(self, path: str):
+        raise ValueError("load_audio: file decoding (torchaudio.load) is outside the MI355X hot path; "
+                         "decode to a float32 tensor and call process()")
+
+    def resample(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
+        if orig_sr == self.sample_rate:
+            return waveform
+        raise ValueError(f"resample: {orig_sr} Hz -> {self.sample_rate} Hz is not implemented on the MI355X path; "
+                         "resample before calling process()")
+
+    def to_mono(self, waveform: torch.Tensor) -> torch.Tensor:
+        if waveform.shape[0] == 1:
+            return waveform
+        return waveform.mean(dim=0, keepdim=True)
+
+    def normalize(self, waveform: torch.Tensor) -> torch.Tensor:
+        """Peak-normalise (silent no-op on an all-zero input).  ``process`` / ``add_audio`` do NOT call
+        this: they set the fused-normalise flag of the kernel instead."""
+        max_val = waveform.abs().max()
+        if max_val > 0:
+            return waveform / max_val
+        return waveform
+
+    def pad_or_trim(self, waveform: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:
+        if length is None:
+            length = self.segment_samples
+        n = waveform.shape[1]
+        if n == length:
+            return waveform
+        if n > length:
+            start = (n - length) // 2
+            return waveform[:, start:start + length]
+        left = (length - n) // 2
+        return torch.nn.functional.pad(waveform, (left, length - n - left), mode="constant", value=0)
+
+    def get_expected_time_frames(self) -> int:
+        return (self.segment_samples // self.hop_length) + 1
+
+    def get_num_features(self) -> int:
+        n = self.n_mels
+        if self.use_mfcc:
+            n += 2 * self.n_mfcc
+            if self.use_delta_delta:
+                n += self.n_mfcc
+        if self.use_spectral_contrast:
+            n += self.n_contrast_bands + 1
+        return n
+
+    # ------------------------------------------------------------------ the hot path
+    def _out_device(self, like: torch.Tensor) -> torch.device:
+        return torch.device("cpu") if str(self.device) == "cpu" else _cuda_device()
+
+    def featurize_batch(self, waveforms: torch.Tensor, normalize: bool = False,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(B, segment_samples) float32 on the GPU -> (B, F, T) float32 on the GPU (stream-ordered,
+        no host sync).  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
+        if waveforms.dim() != 2 or waveforms.shape[1] != self.segment_samples:
+            raise ValueError(f"featurize_batch: expected (B, {self.segment_samples}), got {tuple(waveforms.shape)}")
+        dev = _cuda_device()
+        w = waveforms.to(device=dev, dtype=torch.float32)
+        if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
+            w = w.contiguous()
+        b = w.shape[0]
+        f, t = self.get_num_features(), self.get_expected_time_frames()
+        if out is None:
+            out = torch.empty((b, f, t), dtype=torch.float32, device=dev)
+        elif out.shape != (b, f, t) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("featurize_batch: `out` must be a contiguous float32 (B, F, T) tensor on the GPU")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        stride = w.stride(0) if b > 1 else self.segment_samples
+        _lib.check(_lib.load().cough_featurize(self._native(), w.data_ptr(), stride, out.data_ptr(), b,
+                                               _lib.FEAT_NORMALIZE if normalize else 0, stream),
+                   "cough_featurize")
+        return out
+
+    def extract_features(self, waveform: torch.Tensor) -> torch.Tensor:
+        """(1, N) -> (1, F, T) like the reference; also (B, N) / (B, 1, N) -> (B, F, T)."""
+        if waveform.dim() == 3:
+            if waveform.shape[1] != 1:
+                raise ValueError("extract_features: (B, C, N) input needs C == 1")
+            waveform = waveform[:, 0]
+        if waveform.dim() != 2:
+            raise ValueError(f"extract_features: expected (1, N) or (B, N), got {tuple(waveform.shape)}")
+        if waveform.shape[1] != self.segment_samples:
+            raise ValueError(f"extract_features: the MI355X path takes windows of exactly {self.segment_samples} "
+                             f"samples (got {waveform.shape[1]}); use pad_or_trim() / process()")
+        return self.featurize_batch(waveform).to(self._out_device(waveform))
+
+    def extract_mel_spectrogram(self, waveform: torch.Tensor) -> torch.Tensor:
+        return self.extract_features(waveform)[:, :self.n_mels]
+
+    def extract_mfcc(self, waveform: torch.Tensor) -> torch.Tensor:
+        return self.extract_features(waveform)[:, self.n_mels:self.n_mels + self.n_mfcc]
+
+    def process(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
+        """resample -> mono -> normalize -> pad/trim -> features (normalize fused into the kernel:
+        peak-normalising before a centre trim / zero pad equals doing it on the host first only when
+        the peak lies inside the kept window, so the host normalises when the length changes)."""
+        waveform = self.to_mono(self.resample(waveform, orig_sr))
+        if waveform.shape[1] == self.segment_samples:
+            return self.featurize_batch(waveform, normalize=True).to(self._out_device(waveform))
+        waveform = self.pad_or_trim(self.normalize(waveform))
+        return self.extract_features(waveform)
+
+    def process_file(self, path: str) -> torch.Tensor:
+        return self.process(*self.load_audio(path))
+
+
+class RealtimePreprocessor(AudioPreprocessor):
+    """Sliding-window front end: append chunks, emit one feature image per complete window.
+    All complete windows of a call are featurised by ONE kernel launch (batch = windows)."""
+
+    def __init__(self, window_duration: float = 1.0, hop_duration: float = 0.5, **kwargs):
+        super().__init__(segment_duration=window_duration, **kwargs)
+        self.window_duration = window_duration
+        self.hop_duration = hop_duration
+        self.window_samples = int(self.sample_rate * window_duration)
+        self.hop_samples = int(self.sample_rate * hop_duration)
+        self.buffer = torch.zeros(1, 0)
+
+    def take_windows(self, audio_chunk: torch.Tensor) -> Optional[torch.Tensor]:
+        """Append a chunk; return the raw complete windows as (n, window_samples) or None."""
+        if audio_chunk.dim() == 1:
+            audio_chunk = audio_chunk.unsqueeze(0)
+        self.buffer = torch.cat([self.buffer, audio_chunk.detach().to("cpu", torch.float32)], dim=1)
+        n_avail = self.buffer.shape[1]
+        if n_avail < self.window_samples:
+            return None
+        n_win = (n_avail - self.window_samples) // self.hop_samples + 1
+        windows = self.buffer[0].unfold(0, self.window_samples, self.hop_samples)[:n_win].contiguous()
+        self.buffer = self.buffer[:, n_win * self.hop_samples:]
+        return windows
+
+    def add_audio(self, audio_chunk: torch.Tensor) -> List[torch.Tensor]:
+        windows = self.take_windows(audio_chunk)
+        if windows is None:
+            return []
+        feats = self.featurize_batch(windows, normalize=True).to(self._out_device(windows))
+        return [feats[i:i + 1] for i in range(feats.shape[0])]
+
+    def reset(self):
+        self.buffer = torch.zeros(1, 0)
+
+
+def create_preprocessor(realtime: bool = False, **kwargs) -> AudioPreprocessor:
+    if realtime:
+        return RealtimePreprocessor(**kwargs)
+    return AudioPreprocessor(**kwargs)

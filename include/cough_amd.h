@@ -1,0 +1,143 @@
+/*
+ * cough_amd.h -- C-ABI of the MI355X (gfx950) cough-detector hot path.
+ *
+ * The reference (dataexplorations2026/cough_detector) has no FFI: its hot path is
+ * plain Python on torch tensors.  This header is therefore the boundary a
+ * maintainer binds with ctypes; every entry point names the
+ * reference interface it replaces.  Conventions:
+ *
+ *   - plain pointers and sizes only; `d_` = device (HBM) pointer, otherwise host;
+ *   - every call returns COUGH_OK (0) or a COUGH_E* code; cough_amd_last_error()
+ *     gives the thread-local message (the Python side maps EINVAL/EUNSUPPORTED to
+ *     ValueError as /root/reference/src/model.py:313-314 does, the rest to RuntimeError);
+ *   - launches are stream-ordered on `stream` (a hipStream_t; NULL = default
+ *     stream); no call synchronises the device or allocates device memory except
+ *     the *_create functions;
+ *   - the caller owns every input / output / workspace buffer; handles own only
+ *     their immutable tables (window, twiddles, sparse filterbank, DCT, folded
+ *     and packed conv weights);
+ *   - handles are immutable after creation: any number of host threads may launch
+ *     with the same handle (reference threading: one consumer thread,
+ *     /root/reference/src/inference.py:302-335).
+ */
+#ifndef COUGH_AMD_H
+#define COUGH_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COUGH_AMD_ABI_VERSION 1
+
+#define COUGH_OK 0
+#define COUGH_EINVAL 1        /* bad argument (NULL, negative size, misaligned pointer) */
+#define COUGH_EUNSUPPORTED 2  /* a configuration the HIP path does not implement */
+#define COUGH_EHIP 3          /* a HIP runtime call failed */
+#define COUGH_EWORKSPACE 4    /* workspace smaller than *_workspace_bytes() */
+
+int cough_amd_abi_version(void);
+const char* cough_amd_arch(void);        /* "gfx950" */
+const char* cough_amd_last_error(void);  /* thread-local, never NULL */
+
+/* ------------------------------------------------------------------ featuriser (K1)
+ * Replaces AudioPreprocessor.__init__ / extract_features / normalize
+ * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for the shipped
+ * flags (/root/reference/src/train.py:264-287).  Output row order as the reference
+ * concatenates (:456-487): mel[0:n_mels], MFCC, delta, (delta-delta). */
+typedef struct cough_feat_config {
+    int sample_rate;       /* 16000 */
+    int n_fft;             /* 512 */
+    int hop_length;        /* 160 */
+    int win_length;        /* 400 */
+    int n_mels;            /* 64 */
+    int n_mfcc;            /* 13 */
+    int segment_samples;   /* 16000 */
+    int use_pre_emphasis;  /* preprocessing.py:214-240 */
+    float pre_emphasis_coef;
+    int use_delta_delta;   /* preprocessing.py:471-474 */
+} cough_feat_config;
+
+typedef struct cough_featurizer cough_featurizer;
+
+/* window[win_length], mel_fb[(n_fft/2+1) * n_mels] row-major (freq, mel), dct[n_mels * n_mfcc]
+ * row-major (mel, coeff) are HOST float32 tables built by the caller with the same op
+ * sequence torchaudio uses (T.MelSpectrogram / T.MFCC, preprocessing.py:94-127). */
+int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
+                            const float* window, const float* mel_fb, const float* dct);
+void cough_featurizer_destroy(cough_featurizer* f);
+int cough_featurizer_num_features(const cough_featurizer* f); /* get_num_features(), :536-550 */
+int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_time_frames(), :532-534 */
+
+#define COUGH_FEAT_NORMALIZE 1 /* apply normalize() (peak, per clip) before extract_features */
+
+/* d_wav: n_clips rows of segment_samples float32, row i at d_wav + i*wav_stride (elements,
+ * multiple of 4, base 16-byte aligned).  d_feat: [n_clips][num_features][num_frames] float32.
+ * All reductions (peak, top_db floor, MFCC mean/std) are per clip. */
+int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
+                    float* d_feat, int n_clips, int flags, void* stream);
+
+/* ------------------------------------------------------------------ classifier (K2-K5)
+ * Replaces CoughDetectorResidual.forward / predict and ResidualBlock.forward
+ * (/root/reference/src/model.py:210-293) in eval mode.  Pointers are HOST float32
+ * tensors exactly as stored in the reference state_dict. */
+typedef struct cough_conv_bn {
+    const float* w;       /* conv weight  [Cout][Cin][KH][KW] */
+    const float* b;       /* conv bias    [Cout] */
+    const float* bn_w;    /* BatchNorm weight / bias / running_mean / running_var, [Cout] each */
+    const float* bn_b;
+    const float* bn_mean;
+    const float* bn_var;
+} cough_conv_bn;
+
+typedef struct cough_resblock_weights {
+    cough_conv_bn conv1; /* res_blocks.i.conv1 + bn1 : 3x3 s2 p1 */
+    cough_conv_bn conv2; /* res_blocks.i.conv2 + bn2 : 3x3 s1 p1 */
+    cough_conv_bn skip;  /* res_blocks.i.skip.0 + skip.1 : 1x1 s2 */
+} cough_resblock_weights;
+
+typedef struct cough_resnet_weights {
+    cough_conv_bn stem;              /* conv1.0 + conv1.1 : 7x7 s2 p3, 1 -> 32 */
+    cough_resblock_weights block[2]; /* 32 -> 64, 64 -> 128 */
+    const float* fc_w;               /* fc.2.weight [2][128] */
+    const float* fc_b;               /* fc.2.bias   [2] */
+    float bn_eps;                    /* 1e-5 */
+} cough_resnet_weights;
+
+#define COUGH_DTYPE_FP32 0 /* exact-f32 MFMA (v_mfma_f32_*_f32): CPU-reference numerics */
+#define COUGH_DTYPE_BF16 1 /* bf16 operands, f32 accumulate (stem stays f32) */
+
+typedef struct cough_resnet cough_resnet;
+
+int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype);
+void cough_resnet_destroy(cough_resnet* m);
+size_t cough_resnet_workspace_bytes(const cough_resnet* m, int n_clips, int height, int width);
+
+/* d_feat: [n_clips][1][height][width] float32 (height = num_features, width = num_frames).
+ * d_logits: [n_clips][2].  d_probs ([n_clips][2], softmax) and d_preds ([n_clips] int32, argmax)
+ * may be NULL (model.py:261-265).  d_workspace: >= cough_resnet_workspace_bytes, 256-byte aligned. */
+int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips, int height, int width,
+                         float* d_logits, float* d_probs, int* d_preds,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Parity taps: copy the activation after the stem (which=1), block 0 (2) or block 1 (3) of the
+ * LAST forward on this workspace to d_out as [n_clips][C][H][W] float32. */
+int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips,
+                                 int height, int width, int which, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------ streaming windows (K6)
+ * Device-side counterpart of RealtimePreprocessor.add_audio's FIFO
+ * (/root/reference/src/preprocessing.py:582-616) for many concurrent streams: each stream owns
+ * one ring of ring_len float32 in d_rings[stream][ring_len]; positions are absolute sample
+ * counters (ring index = pos % ring_len). */
+int cough_ring_write(float* d_rings, int ring_len, const float* d_chunks, int chunk_len,
+                     const int* d_stream_ids, const long long* d_write_pos, int n_chunks, void* stream);
+int cough_window_gather(const float* d_rings, int ring_len, const int* d_stream_ids,
+                        const long long* d_start_pos, int n_windows, int window_len,
+                        float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COUGH_AMD_H */

@@ -56,38 +56,3 @@ def predict(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor,
     """M5 -- model.py:261-265."""
     probs = F.softmax(forward(x, sd), dim=1)
     return probs.argmax(dim=1), probs
-
-
-def random_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
-    """A state_dict with the reference's key set / shapes and NON-trivial BN
-    statistics (fresh-init 0/1 stats would not exercise BN folding)."""
-    g = torch.Generator().manual_seed(seed)
-    sd: Dict[str, torch.Tensor] = {}
-
-    def conv(name, co, ci, k):
-        bound = 1.0 / (ci * k * k) ** 0.5
-        sd[name + ".weight"] = (torch.rand(co, ci, k, k, generator=g) * 2 - 1) * bound
-        sd[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
-
-    def bn(name, c):
-        sd[name + ".weight"] = torch.rand(c, generator=g) + 0.5
-        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.2
-        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.2
-        sd[name + ".running_var"] = torch.rand(c, generator=g) * 1.5 + 0.25
-        sd[name + ".num_batches_tracked"] = torch.tensor(100)
-
-    conv("conv1.0", 32, 1, 7)
-    bn("conv1.1", 32)
-    ci = 32
-    for i, co in enumerate((64, 128)):
-        p = f"res_blocks.{i}"
-        conv(p + ".conv1", co, ci, 3)
-        bn(p + ".bn1", co)
-        conv(p + ".conv2", co, co, 3)
-        bn(p + ".bn2", co)
-        conv(p + ".skip.0", co, ci, 1)
-        bn(p + ".skip.1", co)
-        ci = co
-    sd["fc.2.weight"] = (torch.rand(2, 128, generator=g) * 2 - 1) / 128 ** 0.5
-    sd["fc.2.bias"] = (torch.rand(2, generator=g) * 2 - 1) / 128 ** 0.5
-    return sd

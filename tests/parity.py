@@ -1,0 +1,52 @@
+"""Shared parity helpers and edge-case inputs for the GPU tests."""
+import numpy as np
+import torch
+
+from cough_detector_amd import synth
+
+SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+
+# Tolerances (BASELINE.json north_star: "mel/MFCC features within 1e-4 rel, logits within 1e-3 abs,
+# argmax class bit-exact").  Mel rows live in [0, 1] (full scale 1) -> absolute 1e-4; the z-scored
+# MFCC / delta rows are O(1) -> |a-b| <= 1e-4 * max(|b|, 1).
+FEAT_TOL = 1e-4
+LOGIT_TOL = 1e-3
+
+
+def feature_errors(got: torch.Tensor, ref: torch.Tensor):
+    got, ref = got.detach().cpu().float(), ref.detach().cpu().float()
+    mel = (got[..., :64, :] - ref[..., :64, :]).abs().max().item()
+    d = (got[..., 64:, :] - ref[..., 64:, :]).abs()
+    rel = (d / ref[..., 64:, :].abs().clamp(min=1.0)).max().item()
+    return mel, rel
+
+
+def edge_clips() -> dict:
+    """Named (16000,) float32 inputs that exercise the branches of the feature chain."""
+    rng = np.random.default_rng(1234)
+    t = np.arange(16000) / 16000.0
+    out = {}
+    out["zeros"] = np.zeros(16000)
+    burst = np.zeros(16000)
+    burst[6000:8000] = rng.standard_normal(2000) * 0.5
+    out["burst_in_digital_silence"] = burst                  # amin clamp + top_db floor
+    out["tiny_burst"] = burst * 1e-5                          # dB < -80 -> mel rows clamp at 0
+    out["tiny_noise"] = rng.standard_normal(16000) * 1e-6
+    out["dc"] = np.full(16000, 0.7)
+    out["square_full_scale"] = np.sign(np.sin(2 * np.pi * 440 * t))
+    imp = np.zeros(16000)
+    imp[8000] = 1.0
+    out["impulse"] = imp
+    out["sine_1k"] = np.sin(2 * np.pi * 1000 * t)
+    out["chirp"] = np.sin(2 * np.pi * (50 + 3900 * t) * t)
+    out["loud_x100"] = rng.standard_normal(16000) * 100.0
+    edge = np.zeros(16000)
+    edge[:300] = rng.standard_normal(300)
+    edge[-300:] = rng.standard_normal(300)
+    out["energy_at_edges"] = edge                             # reflect padding matters
+    out["ramp"] = np.linspace(-1, 1, 16000)
+    return {k: v.astype(np.float32) for k, v in out.items()}
+
+
+def synth_batch(start: int, count: int, peak_normalize: bool = True) -> torch.Tensor:
+    return torch.from_numpy(synth.make_clips(start, count, peak_normalize=peak_normalize))

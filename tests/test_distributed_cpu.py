@@ -1,0 +1,48 @@
+"""N > 1 path on CPU: world_size-2 / 3 gloo processes exercise the round-robin shard + all-gather."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cough_detector_amd import distributed as cdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx = cdist.local_indices(n_total, rank, world)
+        assert len(idx) == cdist.local_count(n_total, rank, world)
+        # the "logits" of global clip i are (i, -i): any mis-ordering is visible
+        local = torch.stack([idx.float(), -idx.float()], dim=1)
+        full = cdist.gather_logits_round_robin(local, n_total=n_total)
+        want = torch.stack([torch.arange(n_total).float(), -torch.arange(n_total).float()], dim=1)
+        assert torch.equal(full, want), (rank, full[:8])
+        out = torch.empty(n_total, 2)
+        assert cdist.gather_logits_round_robin(local, n_total=n_total, out=out) is out and torch.equal(out, want)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 64), (2, 37), (3, 10)])
+def test_round_robin_gather_gloo(world, n_total):
+    mp.spawn(_worker, args=(world, _free_port(), n_total), nprocs=world, join=True)
+
+
+def test_shard_helpers():
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 8, 9, 4096):
+            counts = [cdist.local_count(n, r, world) for r in range(world)]
+            assert sum(counts) == n and max(counts) - min(counts) <= 1
+            allidx = torch.cat([cdist.local_indices(n, r, world) for r in range(world)]).sort().values
+            assert torch.equal(allidx, torch.arange(n))

@@ -1,0 +1,86 @@
+"""S0/R0/K6: sliding-window engine and device ring buffers vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from cough_detector_amd import _lib, synth
+from oracle import engine as oengine, resnet as ores
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = dict(model_type="residual", sample_rate=16000, n_mels=64, n_fft=512, hop_length=160, win_length=400,
+              f_min=100.0, f_max=4000.0, segment_duration=1.0, n_mfcc=13, use_mfcc=True, use_pcen=False,
+              use_pre_emphasis=False, pre_emphasis_coef=0.97, use_delta_delta=False, use_spectral_contrast=False,
+              n_contrast_bands=6)
+
+
+def make_checkpoint(tmp_path, sd):
+    path = str(tmp_path / "best_model.pt")
+    torch.save({"epoch": 3, "model_state_dict": sd, "optimizer_state_dict": {}, "metrics": {"f1": 0.5},
+                "config": CONFIG}, path)                     # schema of src/train.py:192-198
+    return path
+
+
+def test_engine_matches_oracle_stream(tmp_path):
+    sd = synth.random_state_dict(seed=5)
+    sd["fc.2.bias"] = sd["fc.2.bias"] + torch.tensor([0.0, 0.12])       # probabilities straddle the threshold
+    path = make_checkpoint(tmp_path, sd)
+    now = {"t": 0.0}
+    eng = cda.CoughDetectorInference(path, device="auto", confidence_threshold=0.5, smoothing_window=3,
+                                     debounce_seconds=0.5, verbose=False, clock=lambda: now["t"])
+    ref = oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"])
+    stream = synth.make_stream(9, 6.0)
+    events, ref_events = [], []
+    for i in range(0, len(stream), 1600):                    # 0.1 s chunks, inference.py:259
+        now["t"] = (i + 1600) / 16000.0
+        a = eng.process_audio_chunk(stream[i:i + 1600])
+        b = ref.process_audio_chunk(stream[i:i + 1600])
+        events.append(None if a is None else round(a[1], 3))
+        ref_events.append(None if b is None else round(b[1], 3))
+    assert len(eng.window_probs) == len(ref.window_probs) == 21
+    assert np.abs(np.array(eng.window_probs) - np.array(ref.window_probs)).max() < 1e-3
+    assert [e is None for e in events] == [e is None for e in ref_events]
+    assert any(e is not None for e in events) and any(e is None for e in events[10:])
+    is_cough, p = eng.predict(torch.zeros(1, 90, 101))
+    assert isinstance(is_cough, bool) and 0.0 <= p <= 1.0
+    eng.reset()
+    assert len(eng.prediction_history) == 0 and eng.preprocessor.buffer.shape == (1, 0)
+
+
+def test_engine_rejects_unsupported_checkpoints(tmp_path):
+    sd = synth.random_state_dict(seed=5)
+    path = str(tmp_path / "m.pt")
+    torch.save({"model_state_dict": sd, "config": {**CONFIG, "use_pcen": True}}, path)
+    with pytest.raises(ValueError, match="use_pcen"):
+        cda.CoughDetectorInference(path, verbose=False)
+    torch.save({"model_state_dict": sd, "config": {**CONFIG, "model_type": "small"}}, path)
+    with pytest.raises(ValueError, match="not implemented"):
+        cda.CoughDetectorInference(path, verbose=False)
+
+
+def test_ring_write_and_window_gather():
+    lib = _lib.load()
+    S, R, CH, W = 5, 20000, 1600, 16000
+    rng = np.random.default_rng(0)
+    rings = torch.zeros(S, R, device="cuda")
+    host = np.zeros((S, 0), dtype=np.float32)
+    wpos = 0
+    stream = torch.cuda.current_stream().cuda_stream
+    ids = torch.arange(S, dtype=torch.int32, device="cuda")
+    for step in range(30):                                  # 48000 samples: wraps the 20000-sample ring twice
+        chunk = rng.standard_normal((S, CH)).astype(np.float32)
+        host = np.concatenate([host, chunk], axis=1)
+        pos = torch.full((S,), wpos, dtype=torch.int64, device="cuda")
+        _lib.check(lib.cough_ring_write(rings.data_ptr(), R, torch.from_numpy(chunk).cuda().data_ptr(), CH,
+                                        ids.data_ptr(), pos.data_ptr(), S, stream), "ring_write")
+        wpos += CH
+        if wpos >= W and step % 3 == 0:
+            start = wpos - W - (step % 2) * 800
+            win_ids = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
+            starts = torch.full((3,), start, dtype=torch.int64, device="cuda")
+            out = torch.empty(3, W, device="cuda")
+            _lib.check(lib.cough_window_gather(rings.data_ptr(), R, win_ids.data_ptr(), starts.data_ptr(), 3, W,
+                                               out.data_ptr(), stream), "window_gather")
+            want = host[[4, 0, 2], start:start + W]
+            assert np.array_equal(out.cpu().numpy(), want)

@@ -1,0 +1,133 @@
+"""K1 parity: HIP featuriser (through the C-ABI) vs the CPU oracle, goldens and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from oracle import featurizer as ofeat
+from parity import FEAT_TOL, SHIPPED, edge_clips, feature_errors, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pre():
+    return cda.AudioPreprocessor(device="cuda", **SHIPPED)
+
+
+def test_reference_call_shape_single_clip(pre):
+    w = synth_batch(0, 1)
+    f = pre.extract_features(w)                      # (1, N) -> (1, 90, 101), the reference contract
+    assert f.shape == (1, 90, 101) and f.dtype == torch.float32 and f.is_cuda
+    mel, rel = feature_errors(f, ofeat.extract_features(w))
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+    cpu_pre = cda.AudioPreprocessor(device="cpu", **SHIPPED)
+    assert not cpu_pre.extract_features(w).is_cuda   # device="cpu" returns host tensors like the reference
+
+
+def test_golden_fixture(pre, features_golden):
+    w = synth_batch(0, 12)
+    f = pre.extract_features(w.cuda())
+    mel, rel = feature_errors(f, torch.from_numpy(features_golden["features"]))
+    print(f"golden: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def test_synthetic_mixture_against_oracle(pre):
+    w = synth_batch(100, 96)
+    f = pre.extract_features(w.cuda())
+    ref = ofeat.extract_features_batch(w)
+    mel, rel = feature_errors(f, ref)
+    print(f"synthetic x96: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+@pytest.mark.parametrize("name", sorted(edge_clips().keys()))
+def test_edge_cases(pre, name):
+    w = torch.from_numpy(edge_clips()[name])[None]
+    f = pre.extract_features(w.cuda())
+    assert torch.isfinite(f).all()
+    ref = ofeat.extract_features(w)
+    mel, rel = feature_errors(f, ref)
+    print(f"{name}: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+    if name == "zeros":
+        assert torch.all(f[0, :64] == 0)
+
+
+def test_fused_normalize_matches_reference_order(pre):
+    raw = synth_batch(200, 24, peak_normalize=False) * 0.37
+    raw[5] = 0.0                                      # all-zero clip: normalize is a silent no-op
+    got = pre.featurize_batch(raw.cuda(), normalize=True)
+    ref = ofeat.extract_features_batch(raw, normalize_first=True)
+    mel, rel = feature_errors(got, ref)
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+    scaled = pre.featurize_batch((raw * 7.5).cuda(), normalize=True)     # peak-normalised => scale invariant
+    mel, rel = feature_errors(scaled, got)
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def test_optional_flags_pre_emphasis_and_delta_delta():
+    w = synth_batch(300, 8)
+    for kw in (dict(use_pre_emphasis=True), dict(use_delta_delta=True), dict(use_pre_emphasis=True, use_delta_delta=True)):
+        flags = {**SHIPPED, **kw}
+        p = cda.AudioPreprocessor(device="cuda", **flags)
+        f = p.extract_features(w.cuda())
+        ref = ofeat.extract_features_batch(w, use_pre_emphasis=flags["use_pre_emphasis"],
+                                           use_delta_delta=flags["use_delta_delta"])
+        assert f.shape == ref.shape
+        mel, rel = feature_errors(f, ref)
+        assert mel < FEAT_TOL and rel < FEAT_TOL, kw
+
+
+def test_realtime_add_audio_matches_oracle():
+    rt = cda.RealtimePreprocessor(window_duration=1.0, hop_duration=0.25, device="cuda", **SHIPPED)
+    ow = ofeat.RealtimeWindowerOracle(1.0, 0.25)
+    from cough_detector_amd import synth
+    stream = torch.from_numpy(synth.make_stream(5, 2.5))
+    n = 0
+    for i in range(0, stream.numel(), 1600):
+        got, want = rt.add_audio(stream[i:i + 1600]), ow.add_audio(stream[i:i + 1600])
+        assert len(got) == len(want)
+        for g, r in zip(got, want):
+            assert g.shape == (1, 90, 101)
+            mel, rel = feature_errors(g, r)
+            assert mel < FEAT_TOL and rel < FEAT_TOL
+            n += 1
+    assert n == 7
+
+
+def test_empty_batch_and_strided_input(pre):
+    assert pre.featurize_batch(torch.zeros(0, 16000, device="cuda")).shape == (0, 90, 101)
+    big = torch.zeros(5, 16004, device="cuda")
+    w = synth_batch(40, 5)
+    big[:, :16000] = w.cuda()
+    view = big[:, :16000]                             # row stride 16004 (multiple of 4), no copy needed
+    mel, rel = feature_errors(pre.featurize_batch(view), ofeat.extract_features_batch(w))
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def test_full_size_batch_properties(pre):
+    """BASELINE configs[1]: B = 4096.  Oracle on a sample + size-independent properties on everything."""
+    B = 4096
+    w = synth_batch(1000, B)
+    wd = w.cuda()
+    f = pre.featurize_batch(wd)
+    assert f.shape == (B, 90, 101) and torch.isfinite(f).all()
+    # batch invariance (per-clip reductions, no cross-clip leakage): bit-exact vs small launches
+    idx = torch.tensor([0, 1, 255, 256, 2047, 4095])
+    assert torch.equal(pre.featurize_batch(wd[idx]), f[idx])
+    assert torch.equal(pre.featurize_batch(wd), f)    # deterministic
+    # oracle on a sample
+    sample = torch.arange(0, B, 67)
+    mel, rel = feature_errors(f[sample], ofeat.extract_features_batch(w[sample]))
+    print(f"B=4096 sample: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+    # properties: mel rows in [0,1]; z-scored MFCC has mean 0 / unbiased std 1 per clip; delta rows are
+    # exactly the central difference of the stored MFCC rows
+    assert f[:, :64].min() >= 0 and f[:, :64].max() <= 1
+    z = f[:, 64:77].reshape(B, -1)
+    assert z.mean(dim=1).abs().max() < 1e-4 and (z.std(dim=1) - 1).abs().max() < 1e-4
+    zz = f[:, 64:77]
+    zp = torch.cat([zz[:, :, :1], zz, zz[:, :, -1:]], dim=2)
+    assert torch.equal((zp[:, :, 2:] - zp[:, :, :-2]) / 2, f[:, 77:90])

@@ -1,0 +1,128 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host mirror
+keeps the reference's interface / error behaviour, and the streaming bookkeeping is right.
+No GPU compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from cough_detector_amd import _lib, _tables, preprocessing, synth
+from oracle import featurizer as ofeat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cough_amd.h")).read()
+    declared = set(re.findall(r"\b(cough_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cough_amd_abi_version() == 1
+    assert lib.cough_amd_arch() == b"gfx950"
+
+
+def test_ctypes_structs_match_header_layout():
+    assert ctypes.sizeof(_lib.FeatConfig) == 10 * 4
+    assert ctypes.sizeof(_lib.ConvBN) == 6 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.ResNetWeights) == (7 * 6 + 2) * 8 + 8
+
+
+def test_argument_errors_need_no_gpu():
+    lib = _lib.load()
+    assert lib.cough_featurize(None, None, 16000, None, 1, 0, None) == _lib.EINVAL
+    assert b"NULL" in lib.cough_amd_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(lib.cough_resnet_create(None, None, 0), "x")
+
+
+def test_product_tables_equal_oracle_tables():
+    assert torch.equal(_tables.hann_window(400), ofeat.hann_window())
+    assert torch.equal(_tables.mel_filterbank(257, 100.0, 4000.0, 64, 16000), ofeat.melscale_fbanks())
+    assert torch.equal(_tables.dct_matrix(13, 64), ofeat.create_dct())
+
+
+def test_preprocessor_interface_and_errors():
+    p = cda.AudioPreprocessor(**SHIPPED)
+    assert p.get_num_features() == 90 and p.get_expected_time_frames() == 101
+    assert cda.AudioPreprocessor(**{**SHIPPED, "use_delta_delta": True}).get_num_features() == 103
+    with pytest.raises(ValueError, match="use_pcen"):
+        cda.AudioPreprocessor()                              # reference defaults include PCEN + contrast
+    with pytest.raises(ValueError, match="n_fft"):
+        cda.AudioPreprocessor(n_fft=1024, **SHIPPED)
+    with pytest.raises(ValueError, match="16000"):
+        p.extract_features(torch.zeros(1, 8000))
+    with pytest.raises(ValueError):
+        p.resample(torch.zeros(1, 44100), 44100)
+    x = torch.arange(10.0).reshape(1, 10)
+    assert torch.equal(p.pad_or_trim(x, 4), ofeat.pad_or_trim(x, 4))
+    assert torch.equal(p.pad_or_trim(x, 15), ofeat.pad_or_trim(x, 15))
+    z = torch.zeros(1, 5)
+    assert p.normalize(z) is z
+    assert isinstance(cda.create_preprocessor(realtime=True, **SHIPPED), cda.RealtimePreprocessor)
+
+
+def test_missing_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = cda.AudioPreprocessor(**SHIPPED)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p.extract_features(torch.zeros(1, 16000))
+    m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 90, 101))
+
+
+def test_realtime_window_bookkeeping_matches_oracle():
+    rt = cda.RealtimePreprocessor(window_duration=1.0, hop_duration=0.25, **SHIPPED)
+    ow = ofeat.RealtimeWindowerOracle(1.0, 0.25)
+    stream = torch.from_numpy(synth.make_stream(3, 3.3))
+    rng = np.random.default_rng(0)
+    pos, got = 0, []
+    oracle_windows = []
+    while pos < stream.numel():
+        n = int(rng.choice([1600, 1600, 100, 7000, 20000]))
+        chunk = stream[pos:pos + n]
+        pos += n
+        w = rt.take_windows(chunk)
+        if w is not None:
+            got.extend(w)
+        # the oracle's own loop, capturing the raw windows it would featurise
+        ow.buffer = torch.cat([ow.buffer, chunk[None]], dim=1)
+        while ow.buffer.shape[1] >= 16000:
+            oracle_windows.append(ow.buffer[0, :16000].clone())
+            ow.buffer = ow.buffer[:, 4000:]
+        assert rt.buffer.shape == ow.buffer.shape
+    assert len(got) == len(oracle_windows) > 5
+    for a, b in zip(got, oracle_windows):
+        assert torch.equal(a, b)
+    rt.reset()
+    assert rt.buffer.shape == (1, 0)
+
+
+def test_model_state_dict_contract(resnet_golden):
+    sd, _ = resnet_golden
+    m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd)                                    # strict
+    assert cda.count_parameters(m) == 290370
+    with pytest.raises(ValueError, match="Unknown model type"):
+        cda.create_model("resnet50")
+    with pytest.raises(ValueError, match="not implemented"):
+        cda.create_model("small")
+    m.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m(torch.zeros(1, 1, 90, 101))
+
+
+def test_num_features_from_config():
+    from cough_detector_amd.inference import num_features_from_config
+    shipped = dict(n_mels=64, n_mfcc=13, use_mfcc=True, use_delta_delta=False, use_spectral_contrast=False)
+    assert num_features_from_config(shipped) == 90
+    assert num_features_from_config({}) == 110             # the reference's fall-back defaults
