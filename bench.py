@@ -40,22 +40,35 @@ def cpu_baseline(budget_s: float) -> dict:
     from cough_detector_amd import synth
     from oracle import featurizer as ofeat, resnet as ores
     sd = synth.random_state_dict(seed=3)
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
     wav = torch.from_numpy(synth.make_clips(0, 256, peak_normalize=False))
-    with torch.no_grad():
-        for i in range(8):                                                  # warm-up
+
+    def faithful_leg(seconds):
+        for i in range(4):                                                  # warm-up
             f = ofeat.extract_features(ofeat.normalize(wav[i:i + 1]))
             torch.softmax(ores.forward(f.unsqueeze(0), sd), dim=1)[0, 1].item()
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s:
+        while time.perf_counter() - t0 < seconds:
             w = wav[n % 256:n % 256 + 1]
             f = ofeat.extract_features(ofeat.normalize(w))
             torch.softmax(ores.forward(f.unsqueeze(0), sd), dim=1)[0, 1].item()
             n += 1
-        faithful = n / (time.perf_counter() - t0)
+        return n, n / (time.perf_counter() - t0)
+
+    with torch.no_grad():
+        # batch-1 ops are tiny: the default thread count of a many-core host only adds contention, so
+        # the per-clip loop is timed at 1, 8 and the default number of threads and the best is reported
+        best, n, threads = 0.0, 0, 1
+        for th in sorted({1, min(8, default_threads), default_threads}):
+            torch.set_num_threads(th)
+            cnt, rate = faithful_leg(budget_s / 4)
+            if rate > best:
+                best, n, threads = rate, cnt, th
+        faithful = best
+        torch.set_num_threads(default_threads)
         ofeat.extract_features_batched_fast(wav, normalize_first=True)      # warm-up
         m, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s / 2:
+        while time.perf_counter() - t0 < budget_s / 4:
             f = ofeat.extract_features_batched_fast(wav, normalize_first=True)
             torch.softmax(ores.forward(f.unsqueeze(1), sd), dim=1)
             m += 256
@@ -64,7 +77,7 @@ def cpu_baseline(budget_s: float) -> dict:
             "sample": f"{n} clips, per-clip loop (batch 1, duplicated STFT, softmax.item()) on synthetic 1 s clips; "
                       f"torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical cores",
             "batched_value": round(batched, 1),
-            "batched_sample": f"{m} clips at batch 256, single STFT, all threads"}
+            "batched_sample": f"{m} clips at batch 256, single STFT, {default_threads} threads"}
 
 
 def main():

@@ -12,7 +12,8 @@ __global__ void ring_write_kernel(float* __restrict__ rings, int ring_len, const
     const int c = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= chunk_len) return;
-    const long long p = (wpos[c] + i) % ring_len;
+    long long p = (wpos[c] + i) % ring_len;
+    if (p < 0) p += ring_len;
     rings[(long long)ids[c] * ring_len + p] = chunks[(long long)c * chunk_len + i];
 }
 
@@ -21,7 +22,8 @@ __global__ void window_gather_kernel(const float* __restrict__ rings, int ring_l
     const int w = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= window_len) return;
-    const long long p = (spos[w] + i) % ring_len;
+    long long p = (spos[w] + i) % ring_len;
+    if (p < 0) p += ring_len;
     out[(long long)w * window_len + i] = rings[(long long)ids[w] * ring_len + p];
 }
 

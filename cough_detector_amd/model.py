@@ -126,6 +126,9 @@ class CoughDetectorResidual(nn.Module):
         src_dev = x.device
         xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()
         b, _, hgt, wid = xf.shape
+        if b == 0:
+            z = torch.empty((0, 2), dtype=torch.float32, device=src_dev)
+            return (z, z.clone(), torch.empty((0,), dtype=torch.int32, device=src_dev)) if want_probs else z
         lib, h = _lib.load(), self._native()
         need = lib.cough_resnet_workspace_bytes(h, b, hgt, wid)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:

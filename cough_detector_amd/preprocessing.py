@@ -186,8 +186,10 @@ class AudioPreprocessor:
         f, t = self.get_num_features(), self.get_expected_time_frames()
         if out is None:
             out = torch.empty((b, f, t), dtype=torch.float32, device=dev)
-        elif out.shape != (b, f, t) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        elif tuple(out.shape) != (b, f, t) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
             raise ValueError("featurize_batch: `out` must be a contiguous float32 (B, F, T) tensor on the GPU")
+        if b == 0:
+            return out
         stream = torch.cuda.current_stream(dev).cuda_stream
         stride = w.stride(0) if b > 1 else self.segment_samples
         _lib.check(_lib.load().cough_featurize(self._native(), w.data_ptr(), stride, out.data_ptr(), b,

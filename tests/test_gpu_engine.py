@@ -72,10 +72,11 @@ def test_ring_write_and_window_gather():
         chunk = rng.standard_normal((S, CH)).astype(np.float32)
         host = np.concatenate([host, chunk], axis=1)
         pos = torch.full((S,), wpos, dtype=torch.int64, device="cuda")
-        _lib.check(lib.cough_ring_write(rings.data_ptr(), R, torch.from_numpy(chunk).cuda().data_ptr(), CH,
+        dchunk = torch.from_numpy(chunk).cuda()
+        _lib.check(lib.cough_ring_write(rings.data_ptr(), R, dchunk.data_ptr(), CH,
                                         ids.data_ptr(), pos.data_ptr(), S, stream), "ring_write")
         wpos += CH
-        if wpos >= W and step % 3 == 0:
+        if wpos >= W + 800 and step % 3 == 0:
             start = wpos - W - (step % 2) * 800
             win_ids = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
             starts = torch.full((3,), start, dtype=torch.int64, device="cuda")

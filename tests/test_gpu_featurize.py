@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import cough_detector_amd as cda
-from oracle import featurizer as ofeat
+from oracle import dft64, featurizer as ofeat
 from parity import FEAT_TOL, SHIPPED, edge_clips, feature_errors, synth_batch
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,7 @@ def test_synthetic_mixture_against_oracle(pre):
     ref = ofeat.extract_features_batch(w)
     mel, rel = feature_errors(f, ref)
     print(f"synthetic x96: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
-    assert mel < FEAT_TOL and rel < FEAT_TOL
+    assert mel < 2e-5 and rel < 2e-5          # measured 3e-6 / 2e-6; spec bound is FEAT_TOL = 1e-4
 
 
 @pytest.mark.parametrize("name", sorted(edge_clips().keys()))
@@ -49,8 +49,15 @@ def test_edge_cases(pre, name):
     assert torch.isfinite(f).all()
     ref = ofeat.extract_features(w)
     mel, rel = feature_errors(f, ref)
-    print(f"{name}: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
-    assert mel < FEAT_TOL and rel < FEAT_TOL
+    # conditioning: on inputs whose energy sits entirely in bins 0-1 (dc, ramp) the mel bands hold only
+    # f32 rounding noise 13 orders below the peak, and the f32 CPU path itself is 7e-4 .. 1.5e-3 away
+    # from float64 truth -- no two f32 implementations agree there.  Bound by the oracle's own f64 error.
+    truth = torch.from_numpy(dft64.features(edge_clips()[name])).float()[None]
+    ref_mel, ref_rel = feature_errors(ref, truth)
+    print(f"{name}: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e} (oracle vs f64: {ref_mel:.2e}, {ref_rel:.2e})")
+    assert mel < max(FEAT_TOL, 3 * ref_mel) and rel < max(FEAT_TOL, 3 * ref_rel)
+    if name not in ("dc", "ramp"):
+        assert mel < FEAT_TOL and rel < FEAT_TOL
     if name == "zeros":
         assert torch.all(f[0, :64] == 0)
 
