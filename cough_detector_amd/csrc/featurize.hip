@@ -5,16 +5,22 @@
 // (T.MelSpectrogram :94-106, T.AmplitudeToDB :109-112, T.MFCC :116-127).  The reference runs the
 // STFT->mel->dB chain twice per clip (:398 and :425); here one pass feeds both branches.
 //
-// One workgroup (8 waves) per clip; the whole clip lives in LDS.  All three per-clip reductions
-// (peak for normalize, dB max for top_db, MFCC mean/std) are block reductions, so batches keep the
-// reference's per-clip semantics.
+// One 4-wave workgroup per clip, 43 KB of LDS, so three clips are in flight per CU and their
+// phases overlap (one loads from HBM while another runs FFTs and a third stores).  All three
+// per-clip reductions (peak for normalize, dB max for top_db, MFCC mean/std) are block reductions,
+// so batches keep the reference's per-clip semantics.
 //
-//   P0  stage: coalesced float4 global loads -> (optional peak-normalise) -> LDS, reflect pad 256|N|256
-//   P1  per frame (16 lanes each, 4 frames per wave pass): window * samples, packed as 256 complex
-//       points; 256-pt FFT as radix-16 x radix-16 with ONE LDS transpose; real-input split for
-//       bins 0..127 (lanes i and 16-i trade their upper halves by shuffle); |X|^2 -> LDS;
-//       sparse mel (<=8 taps per band, taps and start bin held in registers); 10*log10 -> LDS
-//   P2  block max -> top_db floor -> mel rows out; 13x64 DCT; mean / unbiased std; z-score, deltas out
+//   P0  (normalize only) peak of the clip: float4 loads, block max; 1/peak is folded into the
+//       per-lane window taps, so normalisation costs nothing per sample
+//   P1  per frame (16 lanes each, 4 frames per wave pass): samples straight from global/L2
+//       (8-byte loads, each sample is touched 2.5x but fetched from HBM once; the 4 edge frames take a
+//       reflected-index path = torch.stft center/reflect), window taps from registers, packed as 256
+//       complex points; 256-pt FFT = radix-16 (registers) -> twiddle (register table) -> LDS transpose
+//       (re then im through the same 17-float-pitch scratch) -> radix-16; real-input split for bins
+//       0..127 (lanes i and 16-i trade their upper halves by ds_bpermute); |X|^2 -> LDS; sparse mel
+//       (lane = band, <= 8 taps + start bin in registers); 10*log10 -> LDS
+//   P2  block max -> top_db floor -> mel rows out; 13x64 DCT with wave-uniform (scalar) coefficients;
+//       mean / unbiased std; z-score, deltas out
 //
 // Only bins 4..127 feed the shipped 100 Hz-4 kHz filterbank, so the upper half
 // of the spectrum is never formed.
@@ -28,15 +34,16 @@ namespace cough {
 namespace {
 
 constexpr int NS = 16000, NFFT = 512, HOP = 160, WIN = 400, NFRAMES = 101, NMEL = 64, NMFCC = 13;
-constexpr int PADL = NFFT / 2, NPAD = NS + 2 * PADL;
+constexpr int PADL = NFFT / 2;
 constexpr int NBIN = 128;   // spectrum bins formed (0..127)
 constexpr int MAXW = 8;     // max non-zero taps of one mel band
-constexpr int THREADS = 512, WAVES = THREADS / 64;
+constexpr int THREADS = 256, WAVES = THREADS / 64;
 constexpr int FPW = 4;      // frames per wave pass
 constexpr int NGROUP = (NFRAMES + FPW - 1) / FPW;
-constexpr int XROW = 17;    // float2 per transpose row (16 + 1 pad: conflict-free ds_read_b64)
+constexpr int XROW = 17;    // floats per transpose row (16 + 1 pad: conflict-free ds_read_b32 / ds_write_b32)
 constexpr int XFRAME = 16 * XROW;
 constexpr int NMF = NMFCC * NFRAMES;  // 1313
+constexpr int FIRST_PLAIN = 2, LAST_PLAIN = 98;   // frames whose 400 live taps lie inside the clip
 
 struct FeatTables {
     float win[NFFT];          // periodic Hann(400) zero-padded 56|400|56
@@ -47,13 +54,12 @@ struct FeatTables {
     float dct_t[NMFCC][NMEL]; // DCT-II ortho, [coeff][mel]
 };
 
-constexpr size_t LDS_PAD = size_t(NPAD) * 4;
-constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 8;
-constexpr size_t LDS_MEL = size_t(NMEL) * NFRAMES * 4;
-constexpr size_t LDS_RED = 64 * 4;
-constexpr size_t LDS_TOTAL = LDS_PAD + LDS_XCH + LDS_MEL + LDS_RED;
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-static_assert(LDS_XCH >= size_t(3) * NMF * 4, "MFCC / delta buffers alias the transpose scratch");
+constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 4;   // 17408
+constexpr size_t LDS_MEL = size_t(NMEL) * NFRAMES * 4;        // 25856
+constexpr size_t LDS_RED = 16 * 4;
+constexpr size_t LDS_TOTAL = LDS_XCH + LDS_MEL + LDS_RED;
+static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
+static_assert(LDS_XCH >= size_t(2) * NMF * 4, "MFCC / delta buffers alias the transpose scratch");
 
 constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, RH = 0.70710678118654752f;
 
@@ -125,106 +131,131 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     return r;
 }
 
-__global__ __launch_bounds__(THREADS) void featurize_kernel(
+#ifdef COUGH_K1_STAMPS
+// Diagnostic build only (tools/k1_stamps.py): per-workgroup s_memtime at phase boundaries, written
+// to a buffer of its own that no other code reads.  Never compiled into libcough_amd.so.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define K1_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        if (g_stamp_buf && threadIdx.x == 0)                                                \
+            g_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define K1_STAMP(slot) do { } while (0)
+#endif
+
+// W32^k2 = exp(-2*pi*i*k2/32), k2 = 0..7 (compile-time constants of the real-input split)
+__device__ constexpr float W32C[8] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                                      0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f,
+                                      0.19509032201612825f};
+__device__ constexpr float W32S[8] = {0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                                      -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f,
+                                      -0.98078528040323043f};
+
+template <bool PRE_EMPH>   // pre-emphasis is a separate instantiation: it never costs the shipped path registers
+__global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
-    const FeatTables* __restrict__ tb, int normalize, int pre_emph, float pre_coef, int delta_delta) {
+    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* pad = reinterpret_cast<float*>(smem);
-    float2* xch = reinterpret_cast<float2*>(smem + LDS_PAD);
-    float* melbuf = reinterpret_cast<float*>(smem + LDS_PAD + LDS_XCH);
-    float* red = reinterpret_cast<float*>(smem + LDS_PAD + LDS_XCH + LDS_MEL);
+    float* xs = reinterpret_cast<float*>(smem);
+    float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
+    float* red = reinterpret_cast<float*>(smem + LDS_XCH + LDS_MEL);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long clip = blockIdx.x;
     const float* x = wav + clip * wav_stride;
     float* o = out + clip * (long long)nfeat * NFRAMES;
 
-    // ---------------- P0: stage the clip ----------------
-    {
-        float4 v[8];
+    K1_STAMP(0);
+    // ---------------- P0: per-clip peak (normalize) ----------------
+    float gain = 1.0f;   // waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212), as x * (1/max)
+    if (normalize) {
         float amax = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
+#pragma unroll 4
+        for (int r = 0; r < (NS / 4 + THREADS - 1) / THREADS; ++r) {
             const int idx = r * THREADS + tid;
-            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NS / 4) v[r] = reinterpret_cast<const float4*>(x)[idx];
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[r].x), fabsf(v[r].y)), fmaxf(fabsf(v[r].z), fabsf(v[r].w))));
-        }
-        if (normalize) {   // waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212)
-            const float m = block_max(amax, red, tid);
-            if (m > 0.f) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { v[r].x /= m; v[r].y /= m; v[r].z /= m; v[r].w /= m; }
+            if (idx < NS / 4) {
+                const float4 v = reinterpret_cast<const float4*>(x)[idx];
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             }
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int idx = r * THREADS + tid;
-            if (idx < NS / 4) reinterpret_cast<float4*>(pad + PADL)[idx] = v[r];
-        }
+        const float m = block_max(amax, red, tid);
+        if (m > 0.f) gain = 1.0f / m;
     }
-    __syncthreads();
-    if (pre_emph) {   // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238); no FMA contraction
-        float y[(NS + THREADS - 1) / THREADS];
-#pragma unroll
-        for (int r = 0; r < (NS + THREADS - 1) / THREADS; ++r) {
-            const int n = r * THREADS + tid;
-            y[r] = 0.f;
-            if (n < NS) y[r] = (n == 0) ? pad[PADL] : __fsub_rn(pad[PADL + n], __fmul_rn(pre_coef, pad[PADL + n - 1]));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < (NS + THREADS - 1) / THREADS; ++r) {
-            const int n = r * THREADS + tid;
-            if (n < NS) pad[PADL + n] = y[r];
-        }
-        __syncthreads();
-    }
-    // reflect padding (torch.stft center=True, pad_mode="reflect"): 512 pad samples, one per thread
-    if (tid < PADL) pad[tid] = pad[2 * PADL - tid];
-    else pad[NS + tid] = pad[NS + 2 * PADL - 2 - tid];   // p = NS+PADL+q <- PADL + (NS-2-q), q = tid-PADL
-    __syncthreads();
+    K1_STAMP(1);
 
     // ---------------- P1: STFT power -> mel -> dB ----------------
     const int j = lane & 15, fsub = lane >> 4;
-    float w_re[16], w_im[16];
+    float w_re[16], w_im[16];   // window taps of this lane's samples (normalisation gain folded in)
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        w_re[n1] = tb->win[32 * n1 + 2 * j];
-        w_im[n1] = tb->win[32 * n1 + 2 * j + 1];
+    for (int n1 = 1; n1 < 15; ++n1) {
+        w_re[n1] = tb->win[32 * n1 + 2 * j] * gain;
+        w_im[n1] = tb->win[32 * n1 + 2 * j + 1] * gain;
     }
     float2 tw_a[16];
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) tw_a[k1] = tb->tw256[j][k1];
-    float2 tw_r[8];
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) tw_r[k2] = tb->tw512[j + 16 * k2];
+    for (int k1 = 1; k1 < 16; ++k1) tw_a[k1] = tb->tw256[j][k1];
+    const float2 tw_j = tb->tw512[j];   // W512^j; W512^(j+16*k2) = W512^j * W32^k2
     float mw[MAXW];
 #pragma unroll
     for (int q = 0; q < MAXW; ++q) mw[q] = tb->mel_w[lane][q];
     const int mstart = tb->mel_start[lane];
 
-    float2* myx = xch + (wave * FPW + fsub) * XFRAME;
+    float* myx = xs + (wave * FPW + fsub) * XFRAME;
     float run_max = -INFINITY;
 
     for (int g = wave; g < NGROUP; g += WAVES) {
-        const int t = FPW * g + fsub;
-        const float* fp = pad + (t < NFRAMES ? t : NFRAMES - 1) * HOP;   // idle sub-frames redo the last frame
+        const int t_raw = FPW * g + fsub;
+        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
+        const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
         float2 a[16];
         a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
         a[15] = make_float2(0.f, 0.f);
+        if constexpr (PRE_EMPH) {
+        } else if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
 #pragma unroll
-        for (int n1 = 1; n1 < 15; ++n1) {
-            const float2 s = *reinterpret_cast<const float2*>(fp + 32 * n1 + 2 * j);
-            a[n1] = make_float2(s.x * w_re[n1], s.y * w_im[n1]);
+            for (int n1 = 1; n1 < 15; ++n1) {
+                const float2 sv = *reinterpret_cast<const float2*>(x + s0 + 32 * n1);
+                a[n1] = make_float2(sv.x * w_re[n1], sv.y * w_im[n1]);
+            }
+        } else {   // frames 0,1,99,100 reach into the reflect padding of torch.stft(center=True)
+#pragma unroll
+            for (int n1 = 1; n1 < 15; ++n1) {
+                int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                a[n1] = make_float2(x[i0] * w_re[n1], x[i1] * w_im[n1]);
+            }
+        }
+        if constexpr (PRE_EMPH) {
+            // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the
+            // reflect padding as the reference does; rare flag -> simple re-gather, no FMA contraction
+#pragma unroll
+            for (int n1 = 1; n1 < 15; ++n1) {
+                int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                const float p0 = i0 > 0 ? __fmul_rn(pre_coef, x[i0 - 1]) : 0.f;
+                const float p1 = i1 > 0 ? __fmul_rn(pre_coef, x[i1 - 1]) : 0.f;
+                a[n1] = make_float2(__fsub_rn(x[i0], p0) * w_re[n1], __fsub_rn(x[i1], p1) * w_im[n1]);
+            }
         }
         dft16(a);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = (k1 == 0) ? a[0] : cmul(a[k1], tw_a[k1]);
-        wave_lds_fence();
+        for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_a[k1]);
+        // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
         float2 z[16];
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) z[n2] = myx[j * XROW + n2];
+        for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) z[n2].x = myx[j * XROW + n2];
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * XROW + n2];
         dft16(z);   // z[k2] = Z[j + 16*k2]
 
         // partner Z[256-k] lives in lane (16-j)&15, register 15-k2 (j>=1) or 16-k2 (j==0)
@@ -236,7 +267,6 @@ __global__ __launch_bounds__(THREADS) void featurize_kernel(
             rv[r].y = __shfl(z[8 + r].y, src, 64);
         }
         wave_lds_fence();
-        float* pf = reinterpret_cast<float*>(myx);
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
             const float2 zk = z[k2];
@@ -244,15 +274,16 @@ __global__ __launch_bounds__(THREADS) void featurize_kernel(
             const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
             const float ex = 0.5f * (zk.x + zp.x), ey = 0.5f * (zk.y - zp.y);
             const float ox = 0.5f * (zk.y + zp.y), oy = -0.5f * (zk.x - zp.x);
-            const float xr = ex + tw_r[k2].x * ox - tw_r[k2].y * oy;
-            const float xi = ey + tw_r[k2].x * oy + tw_r[k2].y * ox;
-            pf[j + 16 * k2] = xr * xr + xi * xi;
+            const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;   // W32^k2 * O
+            const float xr = ex + tw_j.x * qx - tw_j.y * qy;
+            const float xi = ey + tw_j.x * qy + tw_j.y * qx;
+            myx[j + 16 * k2] = xr * xr + xi * xi;
         }
         wave_lds_fence();
         // sparse mel: lane = band, the wave's 4 frames
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
-            const float* p = reinterpret_cast<const float*>(xch + (wave * FPW + f) * XFRAME) + mstart;
+            const float* p = xs + (wave * FPW + f) * XFRAME + mstart;
             float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < MAXW; ++q) acc += mw[q] * p[q];
@@ -266,34 +297,57 @@ __global__ __launch_bounds__(THREADS) void featurize_kernel(
         wave_lds_fence();
     }
 
+    K1_STAMP(2);   // wave 0 finished its frames
     // ---------------- P2: top_db floor, mel rows, DCT, z-score, deltas ----------------
     const float floor_db = block_max(run_max, red, tid) - 80.0f;   // per-clip max
-    for (int idx = tid; idx < NMEL * NFRAMES; idx += THREADS) {
-        const float d = fmaxf(melbuf[idx], floor_db);
-        melbuf[idx] = d;
-        o[idx] = fminf(fmaxf((d + 80.0f) / 80.0f, 0.f), 1.f);      // preprocessing.py:409-410
+    K1_STAMP(3);   // all waves finished P1
+    for (int i2 = tid; i2 < NMEL * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores
+        float2 d = reinterpret_cast<float2*>(melbuf)[i2];
+        d.x = fmaxf(d.x, floor_db);
+        d.y = fmaxf(d.y, floor_db);
+        reinterpret_cast<float2*>(melbuf)[i2] = d;
+        float2 v;
+        v.x = fminf(fmaxf((d.x + 80.0f) / 80.0f, 0.f), 1.f);        // preprocessing.py:409-410
+        v.y = fminf(fmaxf((d.y + 80.0f) / 80.0f, 0.f), 1.f);
+        reinterpret_cast<float2*>(o)[i2] = v;
     }
     __syncthreads();
-    float* mf = reinterpret_cast<float*>(xch);   // [13][101] MFCC, then z-scored in place
-    float* dl = mf + NMF;                        // delta (needed in LDS only for delta-delta)
-    float lsum = 0.f;
-    for (int item = tid; item < NMF; item += THREADS) {
-        const int c = item / NFRAMES, t = item - c * NFRAMES;
-        float acc = 0.f;
-#pragma unroll 16
-        for (int m = 0; m < NMEL; ++m) acc += tb->dct_t[c][m] * melbuf[m * NFRAMES + t];
-        mf[item] = acc;
-        lsum += acc;
+    K1_STAMP(4);   // mel rows written
+    // DCT: thread = (frame t, coefficient half); coefficients are wave-uniform -> scalar loads
+    float* mf = xs;              // [13][101] z-scored MFCC
+    float* dl = mf + NMF;        // delta (needed in LDS only for delta-delta)
+    const int tt = tid & 127;
+    const int chalf = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: c 0..6; waves 2,3: c 7..12
+    const int c0 = chalf * 7, nc = chalf ? 6 : 7;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tt < NFRAMES) {
+        const float* drow = &tb->dct_t[c0][0];
+#pragma unroll 8
+        for (int m = 0; m < NMEL; ++m) {
+            const float v = melbuf[m * NFRAMES + tt];
+#pragma unroll
+            for (int cc = 0; cc < 7; ++cc)
+                if (cc < nc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
+        }
     }
+    float lsum = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc) lsum += (tt < NFRAMES && cc < nc) ? acc[cc] : 0.f;
     const float mean = block_sum(lsum, red, tid) / float(NMF);
+    K1_STAMP(5);   // DCT done
     float lsq = 0.f;
-    for (int item = tid; item < NMF; item += THREADS) {
-        const float d = mf[item] - mean;
-        lsq += d * d;
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc) {
+        const float d = acc[cc] - mean;
+        lsq += (tt < NFRAMES && cc < nc) ? d * d : 0.f;
     }
     const float sd = sqrtf(block_sum(lsq, red, tid) / float(NMF - 1));   // torch.std: unbiased
     const float denom = sd + 1e-8f;                                        // preprocessing.py:428
-    for (int item = tid; item < NMF; item += THREADS) mf[item] = (mf[item] - mean) / denom;
+    if (tt < NFRAMES) {
+#pragma unroll
+        for (int cc = 0; cc < 7; ++cc)
+            if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) / denom;
+    }
     __syncthreads();
     float* o_mfcc = o + NMEL * NFRAMES;
     float* o_delta = o_mfcc + NMF;
@@ -305,6 +359,7 @@ __global__ __launch_bounds__(THREADS) void featurize_kernel(
         o_delta[item] = d;
         if (delta_delta) dl[item] = d;
     }
+    K1_STAMP(6);
     if (delta_delta) {
         __syncthreads();
         float* o_dd = o_delta + NMF;
@@ -373,9 +428,6 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     f->d_tables = nullptr;
     hipError_t e = hipMalloc(&f->d_tables, sizeof(FeatTables));
     if (e == hipSuccess) e = hipMemcpy(f->d_tables, &t, sizeof(FeatTables), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(featurize_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_TOTAL));
     if (e != hipSuccess) {
         set_error("cough_featurizer_create: %s", hipGetErrorString(e));
         if (f->d_tables) (void)hipFree(f->d_tables);
@@ -385,6 +437,12 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     *out = f;
     return COUGH_OK;
 }
+
+#ifdef COUGH_K1_STAMPS
+extern "C" int cough_debug_set_stamp_buffer(void* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
     if (!f) return;
@@ -403,9 +461,15 @@ extern "C" int cough_featurize(const cough_featurizer* f, const float* d_wav, lo
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
     if (n_clips == 0) return COUGH_OK;
-    hipLaunchKernelGGL(featurize_kernel, dim3(n_clips), dim3(THREADS), LDS_TOTAL, static_cast<hipStream_t>(stream),
-                       d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0,
-                       f->cfg.use_pre_emphasis, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta);
+    const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
+    if (f->cfg.use_pre_emphasis)
+        hipLaunchKernelGGL(featurize_kernel<true>, dim3(n_clips), dim3(THREADS), LDS_TOTAL,
+                           static_cast<hipStream_t>(stream), d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
+                           f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta);
+    else
+        hipLaunchKernelGGL(featurize_kernel<false>, dim3(n_clips), dim3(THREADS), LDS_TOTAL,
+                           static_cast<hipStream_t>(stream), d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
+                           f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }

@@ -19,6 +19,7 @@
 // cross-check of the MFMA index math; the Python surface never selects it.
 #include <hip/hip_bf16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -115,6 +116,75 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bn;
             v = fmaxf(v, 0.f);
             if (Po < n_pool) out[Po * STEM_N + r] = from_f32<T>(v);
+        }
+    }
+}
+
+// bf16 stem: one workgroup per clip.  The feature image is converted to bf16 once and staged in LDS
+// with a zero border (rows/cols -3..), so every A fragment is 4 aligned ds_read_b32.  K is re-ordered as
+// 8 kernel rows x 8 taps (7 + one zero tap; the 8th row is all zero): MFMA step s, lane half h <-> kernel
+// row 2s+h, element jj <-> tap jj, i.e. 8 consecutive input pixels of one image row per lane.
+struct StemLds {
+    int nrows, pitch;   // bf16 image in LDS: row = ih + 3, col = iw + 3, pitch even
+    size_t bytes;
+};
+inline StemLds stem_lds(const Shapes& s) {
+    StemLds l;
+    l.nrows = std::max(4 * s.P1h + 6, s.H + 3);
+    l.pitch = (std::max(4 * s.P1w + 6, s.W + 3) + 1) & ~1;
+    l.bytes = size_t(l.nrows) * l.pitch * 2;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w,
+                                                        int nrows, int pitch,
+                                                        const bf16_t* __restrict__ wfrag /* [4][2][32][8] */,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const long long clip = blockIdx.x;
+    const float* src = feat + clip * (long long)H * W;
+    // stage: wave per image row, lanes over columns; zero border included
+    for (int row = wave; row < nrows; row += 4) {
+        const int ih = row - 3;
+        const bool rin = ih >= 0 && ih < H;
+        for (int col = lane; col < pitch; col += 64) {
+            const int iw = col - 3;
+            float v = 0.f;
+            if (rin && iw >= 0 && iw < W) v = src[ih * W + iw];
+            img[row * pitch + col] = f2bf(v);
+        }
+    }
+    bf16x8 bw[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) bw[st] = *reinterpret_cast<const bf16x8*>(wfrag + ((st * 2 + h) * 32 + r) * 8);
+    const float bn = bias[r];
+    __syncthreads();
+
+    const int per_clip = P1h * P1w, n_tiles = (per_clip + 7) / 8;
+    const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
+    bf16_t* o = out + clip * (long long)per_clip * STEM_N;
+    for (int tile = wave; tile < n_tiles; tile += 4) {
+        int P = tile * 8 + q;
+        if (P >= per_clip) P = per_clip - 1;
+        const int ph = P / P1w, pw = P - ph * P1w;
+        // image row of tap row kh: 2*oh + kh, first column 2*ow (both in padded coordinates)
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(img + (2 * (2 * ph + dy) + h) * pitch + 2 * (2 * pw + dx));
+        f32x16 acc = {0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const uint32_t* p = base + st * pitch;   // +2 image rows per step = 2*pitch bf16 = pitch dwords
+            union { uint32_t u[4]; bf16x8 v; } a;
+            a.u[0] = p[0]; a.u[1] = p[1]; a.u[2] = p[2]; a.u[3] = p[3];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[st], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int Po = tile * 8 + 2 * g + h;
+            float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bn;
+            v = fmaxf(v, 0.f);
+            if (Po < per_clip) o[Po * STEM_N + r] = f2bf(v);
         }
     }
 }
@@ -253,6 +323,134 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
     }
 }
 
+// bf16 path: LDS-staged implicit GEMM.  Workgroup tile = 128 output pixels x all N channels; K is the
+// flat index k = (kh*KW + kw)*C + c followed by the C2 channels of the fused 1x1 projection, zero-padded
+// to a multiple of 64 in the packed weights.  Per 64-wide chunk every thread gathers 64 contiguous bytes
+// (32 channels of one tap of one output pixel, zero outside the image) of the A tile and 64 bytes of a
+// weight row into registers TWO chunks ahead of the multiply; chunks pass through two LDS stages with one
+// barrier each.  LDS rows are 144 B (128 + 16 pad): ds_read_b128 of 16 different rows is conflict-free.
+// Waves form a 2(M) x 2(N) grid: each owns 64 rows x N/2 columns.
+constexpr int CG_BM = 128, CG_BK = 64, CG_PITCH = 72;   // pitch in bf16 elements
+
+struct CgRegs {
+    uint4 a[4], b[4];
+};
+
+template <int NT>   // N = 32 * NT
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(ConvArgs<bf16_t> a) {
+    constexpr int N = 32 * NT;
+    constexpr int A_ELEMS = CG_BM * CG_PITCH, B_ELEMS = N * CG_PITCH, STAGE = A_ELEMS + B_ELEMS;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)blockIdx.x * CG_BM;
+    const int per = a.OH * a.OW;
+
+    // this thread's A segment: row tid>>1, channels (tid&1)*32 .. +31 of each chunk
+    const int arow = tid >> 1, seg = (tid & 1) * 32;
+    const long long am = m0 + arow;
+    const bool aok = am < a.M;
+    const long long amc = aok ? am : 0;
+    const int ab = int(amc / per), arem = int(amc - (long long)ab * per);
+    const int aoh = arem / a.OW, aow = arem - aoh * a.OW;
+    const int kmain = a.KH * a.KW * a.C, kreal = kmain + a.C2;
+    const int n_chunks = a.Ktot / CG_BK;   // Ktot is padded to a multiple of 64
+    const bool bload = arow < N;           // N = 64: half the threads carry no B segment
+    const bf16_t* brow = a.wp + (long long)(bload ? arow : 0) * a.Ktot + seg;
+
+    auto load_chunk = [&](int kc, CgRegs& rg) {
+        const int k0 = kc * CG_BK + seg;
+        const bf16_t* p = a.in;   // always readable; `ok` decides whether the data is used
+        bool ok = false;
+        if (k0 < kmain) {
+            const int tap = k0 / a.C, c0 = k0 - tap * a.C;
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+            const int ih = aoh * a.stride - a.pad + kh, iw = aow * a.stride - a.pad + kw;
+            if (aok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+                p = a.in + (((long long)ab * a.H + ih) * a.W + iw) * a.C + c0;
+                ok = true;
+            }
+        } else if (k0 < kreal && aok) {
+            p = a.in2 + (((long long)ab * a.H2 + aoh * a.stride2) * a.W2 + aow * a.stride2) * a.C2 + (k0 - kmain);
+            ok = true;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4*>(p)[q];
+            rg.a[q] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+        if (bload) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rg.b[q] = reinterpret_cast<const uint4*>(brow + kc * CG_BK)[q];
+        }
+    };
+    auto store_chunk = [&](int buf, const CgRegs& rg) {
+        bf16_t* la = lds + buf * STAGE;
+        bf16_t* lb = la + A_ELEMS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(la + arow * CG_PITCH + seg + 8 * q) = rg.a[q];
+        if (bload) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(lb + arow * CG_PITCH + seg + 8 * q) = rg.b[q];
+        }
+    };
+
+    f32x16 acc[2][NT / 2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt) acc[mt][nt] = f32x16{0};
+
+    auto compute = [&](int buf) {
+        const bf16_t* la = lds + buf * STAGE;
+        const bf16_t* lb = la + A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < CG_BK / 16; ++ks) {
+            bf16x8 af[2], bfr[NT / 2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *reinterpret_cast<const bf16x8*>(la + (64 * wm + 32 * mt + r) * CG_PITCH + ks * 16 + 8 * h);
+#pragma unroll
+            for (int nt = 0; nt < NT / 2; ++nt)
+                bfr[nt] = *reinterpret_cast<const bf16x8*>(lb + (wn * (N / 2) + 32 * nt + r) * CG_PITCH + ks * 16 + 8 * h);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT / 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    CgRegs r0, r1;
+    load_chunk(0, r0);
+    if (n_chunks > 1) load_chunk(1, r1);
+    store_chunk(0, r0);
+    __syncthreads();
+    for (int kc = 0; kc < n_chunks; kc += 2) {
+        if (kc + 2 < n_chunks) load_chunk(kc + 2, r0);
+        compute(0);
+        if (kc + 1 < n_chunks) store_chunk(1, r1);
+        __syncthreads();
+        if (kc + 1 >= n_chunks) break;
+        if (kc + 3 < n_chunks) load_chunk(kc + 3, r1);
+        compute(1);
+        if (kc + 2 < n_chunks) store_chunk(0, r0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt) {
+            const int n = wn * (N / 2) + 32 * nt + r;
+            const float bn = a.bias[n];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long mo = m0 + 64 * wm + 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (mo < a.M) a.out[mo * a.N + n] = f2bf(fmaxf(acc[mt][nt][reg] + bn, 0.f));
+            }
+        }
+}
+
 template <typename T>
 __global__ void conv_direct_kernel(ConvArgs<T> a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,6 +552,7 @@ struct cough_resnet {
     int dtype;
     size_t esize;          // activation element size
     float* d_stem_w;       // [50][32]
+    cough::bf16_t* d_stem_wfrag;   // bf16 mode: [4 steps][2 halves][32 n][8 taps] MFMA B fragments
     float* d_stem_b;       // [32]
     void* d_w[4];          // packed [N][Ktot]: b0.conv1, b0.conv2+skip, b1.conv1, b1.conv2+skip
     float* d_b[4];
@@ -373,8 +572,9 @@ int upload(void** dst, const std::vector<T>& v) {
 }
 
 int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const FoldedConv* skip) {
-    const int N = main.N, Km = main.KH * main.KW * main.C, Ks = skip ? skip->C : 0, K = Km + Ks;
-    std::vector<float> w(size_t(N) * K), b(N);
+    const int N = main.N, Km = main.KH * main.KW * main.C, Ks = skip ? skip->C : 0;
+    const int K = (m->esize == 2) ? ((Km + Ks + 63) / 64) * 64 : Km + Ks;   // bf16 GEMM: zero-padded to 64
+    std::vector<float> w(size_t(N) * K, 0.f), b(N);
     for (int n = 0; n < N; ++n) {
         std::memcpy(&w[size_t(n) * K], &main.w[size_t(n) * Km], Km * sizeof(float));
         if (skip) std::memcpy(&w[size_t(n) * K + Km], &skip->w[size_t(n) * Ks], Ks * sizeof(float));
@@ -414,6 +614,10 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     if (m->dtype == COUGH_DTYPE_DIRECT) {
         const long long total = a.M * a.N;
         hipLaunchKernelGGL(conv_direct_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    } else if constexpr (sizeof(T) == 2) {
+        const dim3 grid((unsigned)((a.M + CG_BM - 1) / CG_BM));
+        if (a.N == 64) hipLaunchKernelGGL((conv_gemm_bf16_kernel<2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<4>), grid, dim3(256), 0, st, a);
     } else {
         const long long tiles = (a.M + 31) / 32;
         const dim3 grid((unsigned)((tiles + 3) / 4));
@@ -432,6 +636,12 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     if (m->dtype == COUGH_DTYPE_DIRECT) {
         hipLaunchKernelGGL(stem_direct_kernel<T>, dim3((unsigned)((n_pool * 32 + 255) / 256)), dim3(256), 0, st, d_feat,
                            s.H, s.W, s.P1h, s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
+    } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024) {
+        if constexpr (sizeof(T) == 2) {
+            const StemLds l = stem_lds(s);
+            hipLaunchKernelGGL(stem_bf16_kernel, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w, l.nrows,
+                               l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1));
+        }
     } else {
         const long long tiles = (n_pool + 7) / 8;
         long long blocks = (tiles + 3) / 4;
@@ -498,6 +708,17 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
             for (int k = 0; k < 49; ++k) wk[size_t(k) * 32 + n] = f.w[size_t(n) * 49 + k];
         err = upload(reinterpret_cast<void**>(&m->d_stem_w), wk);
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_stem_b), f.b);
+        if (!err && dtype == COUGH_DTYPE_BF16) {   // B fragments of stem_bf16_kernel: k = 16*st + 8*h + jj <-> (kh = 2*st+h, kw = jj)
+            std::vector<bf16_t> wf(size_t(4) * 2 * 32 * 8, 0);
+            for (int st = 0; st < 4; ++st)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int n = 0; n < 32; ++n)
+                        for (int jj = 0; jj < 7; ++jj) {
+                            const int kh = 2 * st + hh;
+                            if (kh < 7) wf[((size_t(st) * 2 + hh) * 32 + n) * 8 + jj] = f2bf_host(f.w[size_t(n) * 49 + kh * 7 + jj]);
+                        }
+            err = upload(reinterpret_cast<void**>(&m->d_stem_wfrag), wf);
+        }
     }
     const int cin[2] = {32, 64}, cout[2] = {64, 128};
     for (int i = 0; i < 2 && !err; ++i) {
@@ -523,6 +744,7 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
 extern "C" void cough_resnet_destroy(cough_resnet* m) {
     if (!m) return;
     (void)hipFree(m->d_stem_w);
+    (void)hipFree(m->d_stem_wfrag);
     (void)hipFree(m->d_stem_b);
     for (int i = 0; i < 4; ++i) {
         (void)hipFree(m->d_w[i]);
