@@ -307,8 +307,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         d.y = fmaxf(d.y, floor_db);
         reinterpret_cast<float2*>(melbuf)[i2] = d;
         float2 v;
-        v.x = fminf(fmaxf((d.x + 80.0f) / 80.0f, 0.f), 1.f);        // preprocessing.py:409-410
-        v.y = fminf(fmaxf((d.y + 80.0f) / 80.0f, 0.f), 1.f);
+        v.x = fminf(fmaxf((d.x + 80.0f) * 0.0125f, 0.f), 1.f);       // (dB + 80) / 80, preprocessing.py:409-410
+        v.y = fminf(fmaxf((d.y + 80.0f) * 0.0125f, 0.f), 1.f);       // (x * 1/80 is within 1 ulp of x / 80)
         reinterpret_cast<float2*>(o)[i2] = v;
     }
     __syncthreads();
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         lsq += (tt < NFRAMES && cc < nc) ? d * d : 0.f;
     }
     const float sd = sqrtf(block_sum(lsq, red, tid) / float(NMF - 1));   // torch.std: unbiased
-    const float denom = sd + 1e-8f;                                        // preprocessing.py:428
+    const float rdenom = 1.0f / (sd + 1e-8f);                              // (x - mean) / (std + 1e-8), :428
     if (tt < NFRAMES) {
 #pragma unroll
         for (int cc = 0; cc < 7; ++cc)
-            if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) / denom;
+            if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
     }
     __syncthreads();
     float* o_mfcc = o + NMEL * NFRAMES;

@@ -20,6 +20,7 @@
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
+#include <utility>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -120,6 +121,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     }
 }
 
+// q = a / b for 0 <= a < 2^24 via a float reciprocal plus one correction step (no integer divide)
+__device__ __forceinline__ int fdiv(int a, int b, float inv) {
+    int q = __float2int_rz(__int2float_rn(a) * inv);
+    const int rem = a - q * b;
+    q += (rem >= b) ? 1 : 0;
+    q -= (rem < 0) ? 1 : 0;
+    return q;
+}
+
 // bf16 stem: one workgroup per clip.  The feature image is converted to bf16 once and staged in LDS
 // with a zero border (rows/cols -3..), so every A fragment is 4 aligned ds_read_b32.  K is re-ordered as
 // 8 kernel rows x 8 taps (7 + one zero tap; the 8th row is all zero): MFMA step s, lane half h <-> kernel
@@ -145,15 +155,36 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const long long clip = blockIdx.x;
     const float* src = feat + clip * (long long)H * W;
-    // stage: wave per image row, lanes over columns; zero border included
-    for (int row = wave; row < nrows; row += 4) {
-        const int ih = row - 3;
-        const bool rin = ih >= 0 && ih < H;
-        for (int col = lane; col < pitch; col += 64) {
-            const int iw = col - 3;
-            float v = 0.f;
-            if (rin && iw >= 0 && iw < W) v = src[ih * W + iw];
-            img[row * pitch + col] = f2bf(v);
+    // stage: all of this thread's 8-byte global loads are issued first (the clip is one linear run of
+    // H*W floats, 8-byte aligned for every clip when H*W is even), the image is zero-filled meanwhile,
+    // then the pairs are converted to bf16 and written to their (row, col) cells
+    constexpr int SB_MAXL = 20;                      // float2 loads per thread (H*W <= 2*256*20)
+    const int npairs = (H * W + 1) / 2;
+    const bool even = ((H * W) & 1) == 0;
+    float2 pv[SB_MAXL];
+#pragma unroll
+    for (int u = 0; u < SB_MAXL; ++u) {
+        const int p = tid + u * 256;
+        pv[u] = make_float2(0.f, 0.f);
+        if (p < npairs) {
+            if (even) pv[u] = reinterpret_cast<const float2*>(src)[p];
+            else { pv[u].x = src[2 * p]; if (2 * p + 1 < H * W) pv[u].y = src[2 * p + 1]; }
+        }
+    }
+    for (int i = tid; i < nrows * pitch / 8; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = (nrows * pitch / 8) * 8 + tid; i < nrows * pitch; i += 256) img[i] = 0;
+    __syncthreads();
+    const float inv_w = 1.0f / float(W);
+#pragma unroll
+    for (int u = 0; u < SB_MAXL; ++u) {
+        const int e = 2 * (tid + u * 256);
+        if (e < H * W) {
+            const int ih = fdiv(e, W, inv_w), iw = e - ih * W;
+            img[(ih + 3) * pitch + iw + 3] = f2bf(pv[u].x);
+            if (e + 1 < H * W) {
+                const int ih1 = iw + 1 < W ? ih : ih + 1, iw1 = iw + 1 < W ? iw + 1 : 0;
+                img[(ih1 + 3) * pitch + iw1 + 3] = f2bf(pv[u].y);
+            }
         }
     }
     bf16x8 bw[4];
@@ -451,6 +482,272 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(ConvArgs<bf16_t>
         }
 }
 
+// ---------------------------------------------------------------------------- fused residual block (bf16)
+// One workgroup = G clips.  The block input x (NHWC bf16) is staged ONCE in LDS as a zero-bordered image
+// (16-byte channel chunks XOR-swizzled by pixel so ds_read_b128 of 16 consecutive pixels is conflict-free);
+// conv1 (3x3 s2) runs out of that image, its ReLU'd output h is written back into the same LDS region
+// (bordered) and never touches HBM; conv2 (3x3 s1) runs out of h, with the 1x1 stride-2 projection of x
+// (its 2*oh,2*ow pixels were copied to a compact LDS buffer up front) appended to its K loop.  Weights
+// stream global/L2 -> registers (two 64-wide chunks ahead) -> a two-stage LDS ring shared by all waves.
+// GEMM view per workgroup: M = G*OH*OW output pixels (32-row MFMA tiles), N = COUT, K = 9*CIN then
+// 9*COUT + CIN.  Wave (mg, ng) owns MW M-tiles x NW N-tiles.
+template <int C>
+__device__ __forceinline__ int swz_off(int P, int j) {   // bf16 offset of 16-byte chunk j of pixel P
+    constexpr int CH = C / 8, PPR = 16 / CH;             // chunks per pixel, pixels per 256-byte bank row
+    return P * C + 8 * (j ^ ((P / PPR) & (CH - 1)));
+}
+
+struct RbArgs {
+    const bf16_t* x;      // [B][XH][XW][CIN]
+    int XH, XW, OH, OW, n_clips;
+    const bf16_t* w1;     // [COUT][k1tot]  (k = tap*CIN + c, zero-padded to a multiple of 64)
+    const bf16_t* w2;     // [COUT][k2tot]  (k = tap*COUT + c, then CIN projection channels, zero-padded)
+    int k1tot, k2tot;
+    const float* b1;
+    const float* b2;      // conv2 bias + projection bias
+    bf16_t* out;          // [B][OH][OW][COUT]
+};
+
+template <int CIN, int COUT, int G, int MW, int NW, int WAVES>
+struct RbCfg {
+    static constexpr int NT = COUT / 32, NG = NT / NW, MG = WAVES / NG, MTMAX = MG * MW;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int WPITCH = 72;
+    static constexpr int WPIECES = (COUT * 8 + THREADS - 1) / THREADS;   // 16-byte weight pieces per thread per chunk
+    static size_t lds_bytes(int XH, int XW, int OH, int OW) {
+        const size_t img = std::max(size_t(G) * (XH + 2) * (XW + 2) * CIN, size_t(G) * (OH + 2) * (OW + 2) * COUT) * 2;
+        const size_t skip = size_t(MTMAX) * 32 * CIN * 2;
+        const size_t wst = size_t(2) * COUT * WPITCH * 2;
+        return img + skip + wst;
+    }
+};
+
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    return make_uint2(uint32_t(f2bf(a)) | (uint32_t(f2bf(b)) << 16), uint32_t(f2bf(c)) | (uint32_t(f2bf(d)) << 16));
+}
+
+template <int CIN, int COUT, int G, int MW, int NW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
+    using Cfg = RbCfg<CIN, COUT, G, MW, NW, WAVES>;
+    constexpr int THREADS = Cfg::THREADS, WPITCH = Cfg::WPITCH, WPIECES = Cfg::WPIECES;
+    constexpr int CHI = CIN / 8, CHO = COUT / 8;
+    constexpr int K1 = 9 * CIN, K2M = 9 * COUT, K2 = K2M + CIN;
+    constexpr int N1 = (K1 + 63) / 64, N2 = (K2 + 63) / 64, NQ = N1 + N2;   // 64-wide weight chunks
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int XHb = a.XH + 2, XWb = a.XW + 2, OHb = a.OH + 2, OWb = a.OW + 2;
+    const int per = a.OH * a.OW, M = G * per;
+    const size_t img_elems = std::max(size_t(G) * XHb * XWb * CIN, size_t(G) * OHb * OWb * COUT);
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem);                  // x image, later h image
+    bf16_t* skipbuf = img + img_elems;                              // [row][CIN] swizzled by row
+    bf16_t* wst = skipbuf + size_t(Cfg::MTMAX) * 32 * CIN;          // [2][COUT][WPITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int ng = wave % Cfg::NG, mg = wave / Cfg::NG;
+    const int clip0 = blockIdx.x * G;
+
+    // ---- weight pipeline: chunk q -> registers (two chunks ahead) -> LDS ring stage q&1 ----------------
+    struct WRegs { uint4 v[WPIECES]; };
+    auto load_w = [&](int q) -> WRegs {
+        WRegs rg;
+        const bf16_t* src = q < N1 ? a.w1 + q * 64 : a.w2 + (q - N1) * 64;
+        const int stride = q < N1 ? N1 * 64 : N2 * 64;
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const int piece = tid + i * THREADS;
+            const int pc = piece < COUT * 8 ? piece : 0;   // surplus threads re-read piece 0 (never stored)
+            rg.v[i] = *reinterpret_cast<const uint4*>(src + (pc >> 3) * stride + (pc & 7) * 8);
+        }
+        return rg;
+    };
+    auto store_w = [&](int buf, const WRegs rg) {
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const int piece = tid + i * THREADS;
+            if (piece < COUT * 8)
+                *reinterpret_cast<uint4*>(wst + buf * COUT * WPITCH + (piece >> 3) * WPITCH + (piece & 7) * 8) = rg.v[i];
+        }
+    };
+    WRegs w_next = load_w(0), w_next2 = load_w(NQ > 1 ? 1 : 0);
+
+    // ---- stage x: zero border, interior (swizzled), strided copy for the projection -----------------
+    {
+        const int nborder = 2 * XWb + 2 * a.XH;   // border pixels of one clip image
+        const float inv_nb = 1.0f / float(nborder);
+        for (int i = tid; i < G * nborder * CHI; i += THREADS) {
+            const int j = i & (CHI - 1), bi = i / CHI;
+            const int g = fdiv(bi, nborder, inv_nb), bp = bi - g * nborder;
+            int row, col;
+            if (bp < XWb) { row = 0; col = bp; }
+            else if (bp < 2 * XWb) { row = XHb - 1; col = bp - XWb; }
+            else { const int qq = bp - 2 * XWb; row = 1 + (qq >> 1); col = (qq & 1) ? XWb - 1 : 0; }
+            *reinterpret_cast<uint4*>(img + swz_off<CIN>((g * XHb + row) * XWb + col, j)) = make_uint4(0, 0, 0, 0);
+        }
+        const int npix = a.XH * a.XW, total = G * npix * CHI;
+        const float inv_np = 1.0f / float(npix), inv_xw = 1.0f / float(a.XW);
+        const int valid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * npix * CHI;   // pieces of real clips
+        const uint4* src = reinterpret_cast<const uint4*>(a.x + (long long)clip0 * npix * CIN);
+        for (int base = tid; base < total; base += 4 * THREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // the source is one linear run of 16-byte pieces: loads first
+                const int i = base + u * THREADS;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < valid) v[u] = src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * THREADS;
+                if (i >= total) continue;
+                const int j = i & (CHI - 1), pi_all = i / CHI;
+                const int g = fdiv(pi_all, npix, inv_np), pi = pi_all - g * npix;
+                const int y = fdiv(pi, a.XW, inv_xw), xx = pi - y * a.XW;
+                *reinterpret_cast<uint4*>(img + swz_off<CIN>((g * XHb + y + 1) * XWb + xx + 1, j)) = v[u];
+                if (!(y & 1) && !(xx & 1))   // pixel (2*oh, 2*ow) feeds the 1x1 stride-2 projection
+                    *reinterpret_cast<uint4*>(skipbuf + swz_off<CIN>(g * per + (y >> 1) * a.OW + (xx >> 1), j)) = v[u];
+            }
+        }
+    }
+    store_w(0, w_next);
+    w_next = w_next2;
+    __syncthreads();
+
+    // ---- per-lane geometry: lane r owns output pixel R of each of its M-tiles ---------------------------
+    int pr1[MW][3], pr2[MW][3], hs_skip[MW], off_skip[MW], p_h[MW];
+    const float inv_per = 1.0f / float(per), inv_ow = 1.0f / float(a.OW);
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        const int R = (mg * MW + mt) * 32 + r;
+        const int Rc = R < M ? R : M - 1;
+        const int g = fdiv(Rc, per, inv_per), rem = Rc - g * per;
+        const int oh = fdiv(rem, a.OW, inv_ow), ow = rem - oh * a.OW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            pr1[mt][kh] = (g * XHb + 2 * oh + kh) * XWb + 2 * ow;   // x-image pixel of tap (kh, 0)
+            pr2[mt][kh] = (g * OHb + oh + kh) * OWb + ow;           // h-image pixel of tap (kh, 0)
+        }
+        p_h[mt] = pr2[mt][1] + 1;                                    // h-image pixel of the output itself
+        hs_skip[mt] = h ^ ((Rc / (16 / CHI)) & (CHI - 1));
+        off_skip[mt] = Rc * CIN;
+    }
+    const bool active = (mg * MW) * 32 < M;   // waves whose tiles lie beyond M only help with weights / barriers
+
+    // accumulators: operands are swapped (weights = MFMA A, activations = MFMA B), so lane r holds pixel r
+    // and register (reg&3) + 8*(reg>>2) + 4*h is the channel: 4 consecutive channels per register quad
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = f32x16{0};
+
+    const bf16_t* lb_lane = wst + (ng * NW * 32 + r) * WPITCH + 8 * h;
+
+    // One step per 64-wide weight chunk; Q is a compile-time constant so taps / channel offsets fold away.
+    auto step = [&]<int q>() {
+        if constexpr (q == N1) {
+            // ---- h = ReLU(conv1 + b1) -> bordered h image over the (now dead) x image -------------------
+            const int nborder = 2 * OWb + 2 * a.OH;
+            const float inv_nb = 1.0f / float(nborder);
+            for (int i = tid; i < G * nborder * CHO; i += THREADS) {
+                const int j = i & (CHO - 1), bi = i / CHO;
+                const int g = fdiv(bi, nborder, inv_nb), bp = bi - g * nborder;
+                int row, col;
+                if (bp < OWb) { row = 0; col = bp; }
+                else if (bp < 2 * OWb) { row = OHb - 1; col = bp - OWb; }
+                else { const int qq = bp - 2 * OWb; row = 1 + (qq >> 1); col = (qq & 1) ? OWb - 1 : 0; }
+                *reinterpret_cast<uint4*>(img + swz_off<COUT>((g * OHb + row) * OWb + col, j)) = make_uint4(0, 0, 0, 0);
+            }
+            if (active) {
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt) {
+                    const bool rok = (mg * MW + mt) * 32 + r < M;
+#pragma unroll
+                    for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int n0 = (ng * NW + nt) * 32 + 8 * gq + 4 * h;
+                            const float4 bb = *reinterpret_cast<const float4*>(a.b1 + n0);
+                            const uint2 pk = pack4_bf16(fmaxf(acc[mt][nt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][nt][4 * gq + 1] + bb.y, 0.f),
+                                                        fmaxf(acc[mt][nt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][nt][4 * gq + 3] + bb.w, 0.f));
+                            if (rok) *reinterpret_cast<uint2*>(img + swz_off<COUT>(p_h[mt], n0 >> 3) + (n0 & 7)) = pk;
+                        }
+#pragma unroll
+                    for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = f32x16{0};
+                }
+            }
+            __syncthreads();
+        }
+        const WRegs w_load = load_w(q + 2 < NQ ? q + 2 : q);
+        if (active) {
+            const bf16_t* lb = lb_lane + (q & 1) * COUT * WPITCH;
+            auto kstep = [&]<int ks>() {
+                constexpr int kg = (q < N1 ? q : q - N1) * 64 + ks * 16;
+                if constexpr ((q < N1 && kg >= K1) || (q >= N1 && kg >= K2)) return;   // zero-padded tail of K
+                bf16x8 af[MW], bfr[NW];
+                if constexpr (q < N1) {
+                    constexpr int tap = kg / CIN, c16 = (kg % CIN) / 16, kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                    for (int mt = 0; mt < MW; ++mt) {
+                        const int P = pr1[mt][kh] + kw;
+                        const int hs = h ^ ((P / (16 / CHI)) & (CHI - 1));
+                        af[mt] = *reinterpret_cast<const bf16x8*>(img + P * CIN + 8 * ((2 * c16) ^ hs));
+                    }
+                } else if constexpr (kg < K2M) {
+                    constexpr int tap = kg / COUT, c16 = (kg % COUT) / 16, kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                    for (int mt = 0; mt < MW; ++mt) {
+                        const int P = pr2[mt][kh] + kw;
+                        const int hs = h ^ ((P / (16 / CHO)) & (CHO - 1));
+                        af[mt] = *reinterpret_cast<const bf16x8*>(img + P * COUT + 8 * ((2 * c16) ^ hs));
+                    }
+                } else {
+                    constexpr int c16 = (kg - K2M) / 16;
+#pragma unroll
+                    for (int mt = 0; mt < MW; ++mt)
+                        af[mt] = *reinterpret_cast<const bf16x8*>(skipbuf + off_skip[mt] + 8 * ((2 * c16) ^ hs_skip[mt]));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NW; ++nt)
+                    bfr[nt] = *reinterpret_cast<const bf16x8*>(lb + nt * 32 * WPITCH + ks * 16);
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NW; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            };
+            kstep.template operator()<0>();
+            kstep.template operator()<1>();
+            kstep.template operator()<2>();
+            kstep.template operator()<3>();
+        }
+        if constexpr (q + 1 < NQ) store_w((q + 1) & 1, w_next);
+        __syncthreads();
+        w_next = w_load;
+    };
+    [&]<int... Qs>(std::integer_sequence<int, Qs...>) {
+        (step.template operator()<Qs>(), ...);
+    }(std::make_integer_sequence<int, NQ>{});
+
+    // ---- epilogue: out = ReLU(conv2 + projection + b2), 8-byte stores of 4 consecutive channels ---------
+    if (active) {
+        bf16_t* o = a.out + (long long)clip0 * per * COUT;
+        const int mvalid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * per;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            const int R = (mg * MW + mt) * 32 + r;
+#pragma unroll
+            for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n0 = (ng * NW + nt) * 32 + 8 * gq + 4 * h;
+                    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
+                    const uint2 pk = pack4_bf16(fmaxf(acc[mt][nt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][nt][4 * gq + 1] + bb.y, 0.f),
+                                                fmaxf(acc[mt][nt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][nt][4 * gq + 3] + bb.w, 0.f));
+                    if (R < mvalid) *reinterpret_cast<uint2*>(o + (long long)R * COUT + n0) = pk;
+                }
+        }
+    }
+}
+
 template <typename T>
 __global__ void conv_direct_kernel(ConvArgs<T> a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,7 +933,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     if (m->dtype == COUGH_DTYPE_DIRECT) {
         hipLaunchKernelGGL(stem_direct_kernel<T>, dim3((unsigned)((n_pool * 32 + 255) / 256)), dim3(256), 0, st, d_feat,
                            s.H, s.W, s.P1h, s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
-    } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024) {
+    } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
             hipLaunchKernelGGL(stem_bf16_kernel, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w, l.nrows,
@@ -656,6 +953,27 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                         {w.a2, w.h1, w.a3, s.B0h, s.B0w, s.B1h, s.B1w, 64, 128, 2, 3}};
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
+        if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
+            using Cfg0 = RbCfg<32, 64, 2, 1, 2, 9>;
+            using Cfg1 = RbCfg<64, 128, 4, 3, 1, 8>;
+            RbArgs ra{};
+            ra.x = reinterpret_cast<const bf16_t*>(k.x); ra.XH = k.xh; ra.XW = k.xw; ra.OH = k.oh; ra.OW = k.ow;
+            ra.n_clips = n;
+            ra.w1 = reinterpret_cast<const bf16_t*>(m->d_w[k.s1]); ra.k1tot = m->ktot[k.s1]; ra.b1 = m->d_b[k.s1];
+            ra.w2 = reinterpret_cast<const bf16_t*>(m->d_w[k.s2]); ra.k2tot = m->ktot[k.s2]; ra.b2 = m->d_b[k.s2];
+            ra.out = reinterpret_cast<bf16_t*>(k.out);
+            const size_t lds = i == 0 ? Cfg0::lds_bytes(k.xh, k.xw, k.oh, k.ow) : Cfg1::lds_bytes(k.xh, k.xw, k.oh, k.ow);
+            const int g = i == 0 ? 2 : 4, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
+            if (m->dtype == COUGH_DTYPE_BF16 && lds <= 160 * 1024 && g * k.oh * k.ow <= mtmax * 32) {
+                const dim3 grid((unsigned)((n + g - 1) / g));
+                if (i == 0)
+                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 2, 1, 2, 9>), grid, dim3(Cfg0::THREADS), lds, st, ra);
+                else
+                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 4, 3, 1, 8>), grid, dim3(Cfg1::THREADS), lds, st, ra);
+                COUGH_HIP_CHECK(hipGetLastError());
+                continue;
+            }
+        }
         ConvArgs<T> c1{};
         c1.in = reinterpret_cast<const T*>(k.x); c1.H = k.xh; c1.W = k.xw; c1.C = k.cin;
         c1.KH = 3; c1.KW = 3; c1.stride = 2; c1.pad = 1;
@@ -732,6 +1050,17 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         std::vector<float> fw(w->fc_w, w->fc_w + 256), fb(w->fc_b, w->fc_b + 2);
         err = upload(reinterpret_cast<void**>(&m->d_fcw), fw);
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_fcb), fb);
+    }
+    if (!err && dtype == COUGH_DTYPE_BF16) {   // the fused block kernels use more than 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 2, 1, 2, 9>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 4, 3, 1, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("cough_resnet_create: %s", hipGetErrorString(e));
+            err = COUGH_EHIP;
+        }
     }
     if (err) {
         cough_resnet_destroy(m);
