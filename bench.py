@@ -33,6 +33,21 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
 
+def measured_traffic(batch: int):
+    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (tools/pmc_k1.sh ->
+    tools/pmc_to_json.py; FETCH_SIZE doubled per the gfx950 calibration).  PMC cannot be collected from
+    inside this process, so the figure is read from profiles/ and only used when the batch matches."""
+    path = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    try:
+        with open(path) as f:
+            p = json.load(f)
+        if p["clips_per_launch"] == batch:
+            return int(p["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def cpu_baseline(budget_s: float) -> dict:
     """Reference-faithful CPU path (per-clip loop, batch 1, STFT computed twice, softmax(...).item(),
     as src/preprocessing.py:398,425 + src/inference.py:216-217) and a best-effort batched CPU path,
@@ -162,6 +177,7 @@ def main():
     if rank == 0:
         total_clips = world * B * K
         achieved = B * BYTES_PER_CLIP / (k1_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(B)
         line = {
             "metric": "1s@16kHz clips/sec (featurise+infer)" if not args.featurize_only
                       else "1s@16kHz clips/sec (featurise only)",
@@ -179,7 +195,7 @@ def main():
                        "weights": "random-init, BN stats randomised"},
             "roofline": {"kernel": "featurize_kernel (K1)", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "ms_per_launch": round(k1_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": round(k1_ms, 4),
                          "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP},
         }
         if not args.featurize_only:

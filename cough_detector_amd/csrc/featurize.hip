@@ -10,8 +10,10 @@
 // per-clip reductions (peak for normalize, dB max for top_db, MFCC mean/std) are block reductions,
 // so batches keep the reference's per-clip semantics.
 //
-//   P0  (normalize only) peak of the clip: float4 loads, block max; 1/peak is folded into the
-//       per-lane window taps, so normalisation costs nothing per sample
+//   P0  none.  Peak normalisation (x / max|x|) commutes with everything up to the dB stage:
+//       power scales by 1/peak^2, so dB(x/peak) = max(dB(x) - 20*log10(peak), -100) (the -100 is the
+//       reference's amin = 1e-10 clamp).  The peak is collected from the samples the frames load anyway
+//       (every sample lies under some frame's live taps), so the clip is read from HBM exactly once.
 //   P1  per frame (16 lanes each, 4 frames per wave pass): samples straight from global/L2
 //       (8-byte loads, each sample is touched 2.5x but fetched from HBM once; the 4 edge frames take a
 //       reflected-index path = torch.stft center/reflect), window taps from registers, packed as 256
@@ -57,7 +59,8 @@ struct FeatTables {
 constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 4;   // 17408
 constexpr size_t LDS_MEL = size_t(NMEL) * NFRAMES * 4;        // 25856
 constexpr size_t LDS_RED = 16 * 4;
-constexpr size_t LDS_TOTAL = LDS_XCH + LDS_MEL + LDS_RED;
+constexpr size_t LDS_TW = size_t(16) * XROW * 8;              // W256^(j*k1) table, 17-float2 row pitch
+constexpr size_t LDS_TOTAL = LDS_XCH + LDS_MEL + LDS_RED + LDS_TW;
 static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
 static_assert(LDS_XCH >= size_t(2) * NMF * 4, "MFCC / delta buffers alias the transpose scratch");
 
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     float* xs = reinterpret_cast<float*>(smem);
     float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
     float* red = reinterpret_cast<float*>(smem + LDS_XCH + LDS_MEL);
+    float2* twl = reinterpret_cast<float2*>(smem + LDS_XCH + LDS_MEL + LDS_RED);   // [16][XROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long clip = blockIdx.x;
@@ -167,34 +171,19 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     float* o = out + clip * (long long)nfeat * NFRAMES;
 
     K1_STAMP(0);
-    // ---------------- P0: per-clip peak (normalize) ----------------
-    float gain = 1.0f;   // waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212), as x * (1/max)
-    if (normalize) {
-        float amax = 0.f;
-#pragma unroll 4
-        for (int r = 0; r < (NS / 4 + THREADS - 1) / THREADS; ++r) {
-            const int idx = r * THREADS + tid;
-            if (idx < NS / 4) {
-                const float4 v = reinterpret_cast<const float4*>(x)[idx];
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            }
-        }
-        const float m = block_max(amax, red, tid);
-        if (m > 0.f) gain = 1.0f / m;
-    }
     K1_STAMP(1);
 
     // ---------------- P1: STFT power -> mel -> dB ----------------
     const int j = lane & 15, fsub = lane >> 4;
-    float w_re[16], w_im[16];   // window taps of this lane's samples (normalisation gain folded in)
+    float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
 #pragma unroll
     for (int n1 = 1; n1 < 15; ++n1) {
-        w_re[n1] = tb->win[32 * n1 + 2 * j] * gain;
-        w_im[n1] = tb->win[32 * n1 + 2 * j + 1] * gain;
+        w_re[n1] = tb->win[32 * n1 + 2 * j];
+        w_im[n1] = tb->win[32 * n1 + 2 * j + 1];
     }
-    float2 tw_a[16];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) tw_a[k1] = tb->tw256[j][k1];
+    twl[(tid >> 4) * XROW + (tid & 15)] = tb->tw256[tid >> 4][tid & 15];   // 256 threads = 16 x 16 entries
+    __syncthreads();
+    const float2* tw_row = twl + j * XROW;   // row pitch 17 float2: the 16 lanes of a frame hit 16 distinct banks
     const float2 tw_j = tb->tw512[j];   // W512^j; W512^(j+16*k2) = W512^j * W32^k2
     float mw[MAXW];
 #pragma unroll
@@ -202,7 +191,30 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const int mstart = tb->mel_start[lane];
 
     float* myx = xs + (wave * FPW + fsub) * XFRAME;
-    float run_max = -INFINITY;
+    float run_max = -INFINITY;   // max raw dB seen by this lane
+    float peak = 0.f;            // max |sample| seen by this lane
+    // Frame samples are fetched one group AHEAD of their use (28 VGPRs): the HBM/L2 latency of a
+    // group's 14 eight-byte loads hides behind the ~600 VALU instructions of the previous group, and every
+    // byte of the clip is requested from HBM once.
+    auto load_group = [&](int g, float2 (&raw)[16]) {
+        const int t_raw = FPW * g + fsub;
+        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
+        const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
+        if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
+#pragma unroll
+            for (int n1 = 1; n1 < 15; ++n1) raw[n1] = *reinterpret_cast<const float2*>(x + s0 + 32 * n1);
+        } else {   // frames 0,1,99,100 reach into the reflect padding of torch.stft(center=True)
+#pragma unroll
+            for (int n1 = 1; n1 < 15; ++n1) {
+                int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                raw[n1] = make_float2(x[i0], x[i1]);
+            }
+        }
+    };
+    float2 raw[16];
+    if constexpr (!PRE_EMPH) load_group(wave, raw);
 
     for (int g = wave; g < NGROUP; g += WAVES) {
         const int t_raw = FPW * g + fsub;
@@ -211,21 +223,15 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         float2 a[16];
         a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
         a[15] = make_float2(0.f, 0.f);
-        if constexpr (PRE_EMPH) {
-        } else if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
+        if constexpr (!PRE_EMPH) {
 #pragma unroll
             for (int n1 = 1; n1 < 15; ++n1) {
-                const float2 sv = *reinterpret_cast<const float2*>(x + s0 + 32 * n1);
-                a[n1] = make_float2(sv.x * w_re[n1], sv.y * w_im[n1]);
+                peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));
+                a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
             }
-        } else {   // frames 0,1,99,100 reach into the reflect padding of torch.stft(center=True)
-#pragma unroll
-            for (int n1 = 1; n1 < 15; ++n1) {
-                int i0 = s0 + 32 * n1, i1 = i0 + 1;
-                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
-                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
-                a[n1] = make_float2(x[i0] * w_re[n1], x[i1] * w_im[n1]);
-            }
+            // the raw registers are free again: the next group's samples start moving now and land while
+            // this group's FFT / mel / log run
+            if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
         }
         if constexpr (PRE_EMPH) {
             // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the
@@ -237,12 +243,14 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
                 const float p0 = i0 > 0 ? __fmul_rn(pre_coef, x[i0 - 1]) : 0.f;
                 const float p1 = i1 > 0 ? __fmul_rn(pre_coef, x[i1 - 1]) : 0.f;
-                a[n1] = make_float2(__fsub_rn(x[i0], p0) * w_re[n1], __fsub_rn(x[i1], p1) * w_im[n1]);
+                const float x0 = x[i0], x1 = x[i1];
+                peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));   // the peak is of x, not of the emphasised signal
+                a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
             }
         }
         dft16(a);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_a[k1]);
+        for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
         // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
         float2 z[16];
 #pragma unroll
@@ -272,8 +280,10 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             const float2 zk = z[k2];
             const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
             const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
-            const float ex = 0.5f * (zk.x + zp.x), ey = 0.5f * (zk.y - zp.y);
-            const float ox = 0.5f * (zk.y + zp.y), oy = -0.5f * (zk.x - zp.x);
+            // 2*X[k] = (Zk + conj Zp) - i*W512^k*(Zk - conj Zp); the factor 1/2 (1/4 in power) is folded
+            // into the mel taps at create time (exact: a power of two)
+            const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+            const float ox = zk.y + zp.y, oy = zp.x - zk.x;
             const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;   // W32^k2 * O
             const float xr = ex + tw_j.x * qx - tw_j.y * qy;
             const float xi = ey + tw_j.x * qy + tw_j.y * qx;
@@ -289,7 +299,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             for (int q = 0; q < MAXW; ++q) acc += mw[q] * p[q];
             const int tf = FPW * g + f;
             if (tf < NFRAMES) {
-                const float db = 10.0f * log10f(fmaxf(acc, 1e-10f));   // AmplitudeToDB('power'), amin 1e-10
+                // raw dB = 10*log10(acc) = 3.0103*log2(acc) on the hardware log2 (|error| ~1e-6 dB);
+                // -inf for 0: amin and normalisation are applied in P2
+                const float db = 3.01029995663981195f * __log2f(acc);
                 melbuf[lane * NFRAMES + tf] = db;
                 run_max = fmaxf(run_max, db);
             }
@@ -299,12 +311,19 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 
     K1_STAMP(2);   // wave 0 finished its frames
     // ---------------- P2: top_db floor, mel rows, DCT, z-score, deltas ----------------
-    const float floor_db = block_max(run_max, red, tid) - 80.0f;   // per-clip max
+    const float raw_max = block_max(run_max, red, tid);
+    float shift = 0.f;   // 20*log10(peak): waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212)
+    if (normalize) {
+        const float m = block_max(peak, red, tid);
+        if (m > 0.f) shift = 20.0f * log10f(m);
+    }
+    // AmplitudeToDB('power', top_db=80): amin = 1e-10 <=> -100 dB; the floor is relative to the per-clip max
+    const float floor_db = fmaxf(raw_max - shift, -100.0f) - 80.0f;
     K1_STAMP(3);   // all waves finished P1
     for (int i2 = tid; i2 < NMEL * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores
         float2 d = reinterpret_cast<float2*>(melbuf)[i2];
-        d.x = fmaxf(d.x, floor_db);
-        d.y = fmaxf(d.y, floor_db);
+        d.x = fmaxf(fmaxf(d.x - shift, -100.0f), floor_db);
+        d.y = fmaxf(fmaxf(d.y - shift, -100.0f), floor_db);
         reinterpret_cast<float2*>(melbuf)[i2] = d;
         float2 v;
         v.x = fminf(fmaxf((d.x + 80.0f) * 0.0125f, 0.f), 1.f);       // (dB + 80) / 80, preprocessing.py:409-410
@@ -417,7 +436,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                       "(f_max <= sample_rate/4)", m, first, last);
         if (first > NBIN - MAXW) first = NBIN - MAXW;   // keep start+8 inside the power buffer
         t.mel_start[m] = first;
-        for (int q = 0; q < MAXW; ++q) t.mel_w[m][q] = mel_fb[(first + q) * NMEL + m];
+        for (int q = 0; q < MAXW; ++q) t.mel_w[m][q] = 0.25f * mel_fb[(first + q) * NMEL + m];   // |2X|^2 / 4
     }
     for (int c = 0; c < NMFCC; ++c)
         for (int m = 0; m < NMEL; ++m) t.dct_t[c][m] = dct[m * NMFCC + c];
