@@ -55,7 +55,8 @@ def cpu_baseline(budget_s: float) -> dict:
     from cough_detector_amd import synth
     from oracle import featurizer as ofeat, resnet as ores
     sd = synth.random_state_dict(seed=3)
-    default_threads = torch.get_num_threads()
+    from cough_detector_amd.hostcpu import cpu_share
+    default_threads = max(1, min(torch.get_num_threads(), cpu_share()))
     wav = torch.from_numpy(synth.make_clips(0, 256, peak_normalize=False))
 
     def faithful_leg(seconds):
@@ -90,7 +91,7 @@ def cpu_baseline(budget_s: float) -> dict:
         batched = m / (time.perf_counter() - t0)
     return {"value": round(faithful, 1), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"{n} clips, per-clip loop (batch 1, duplicated STFT, softmax.item()) on synthetic 1 s clips; "
-                      f"torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical cores",
+                      f"torch {torch.__version__} CPU, {threads} threads (cgroup share {cpu_share()} of {os.cpu_count()} logical CPUs)",
             "batched_value": round(batched, 1),
             "batched_sample": f"{m} clips at batch 256, single STFT, {default_threads} threads"}
 
@@ -113,6 +114,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    from cough_detector_amd.hostcpu import bound_torch_threads
+    bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

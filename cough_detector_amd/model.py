@@ -64,6 +64,7 @@ class CoughDetectorResidual(nn.Module):
         self.fc = nn.Sequential(nn.Flatten(), nn.Dropout(dropout), nn.Linear(channels[-1], num_classes))
         self._handle: Optional[C.c_void_p] = None
         self._handle_key = None
+        self._tensors = None
         self._workspace: Optional[torch.Tensor] = None
         self.eval()
 
@@ -72,10 +73,19 @@ class CoughDetectorResidual(nn.Module):
 
     # ------------------------------------------------------------------ native handle
     def _weights_key(self):
-        return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict().values())
+        # cheap per-call staleness check: identity + in-place version counter of every weight tensor
+        # (load_state_dict copies in place and bumps _version; .to()/.cuda() replace .data)
+        if self._tensors is None:
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self._tensors)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._tensors = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _release(self):
-        h, self._handle = self._handle, None
+        h = self.__dict__.get("_handle")
+        self.__dict__["_handle"] = None          # bypass nn.Module.__setattr__ (safe during interpreter teardown)
         if h is not None:
             try:
                 _lib.load().cough_resnet_destroy(h)
@@ -83,7 +93,10 @@ class CoughDetectorResidual(nn.Module):
                 pass
 
     def __del__(self):
-        self._release()
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def _native(self) -> C.c_void_p:
         key = self._weights_key()

@@ -1,0 +1,118 @@
+"""Many concurrent audio streams on one GPU (BASELINE.json configs[4]).
+
+The reference serves ONE stream: ``RealtimePreprocessor.add_audio`` keeps a host FIFO, cuts 1 s windows
+every ``hop`` samples (``/root/reference/src/preprocessing.py:597-610``) and
+``CoughDetectorInference.process_audio_chunk`` smooths / debounces the per-window probabilities
+(``/root/reference/src/inference.py:191-241``).  Here S streams share the device:
+
+* samples live in device ring buffers (K6 ``cough_ring_write``); the host keeps only two absolute sample
+  counters per stream (written, next window start);
+* each ``push`` assembles every window that just completed, over all streams, with ONE
+  ``cough_window_gather``, ONE featurise launch (normalisation fused) and ONE classifier forward;
+* the only host<->device traffic per tick is the chunk upload and one (n_windows,) probability download;
+* smoothing (deque mean), threshold, debounce and the "drop the rest of this chunk's windows after a
+  detection" rule are the reference's, per stream, on an injectable clock.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .preprocessing import AudioPreprocessor
+
+SHIPPED_FLAGS = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+
+
+class MultiStreamDetector:
+    def __init__(self, model, n_streams: int, sample_rate: int = 16000, window_duration: float = 1.0,
+                 hop_duration: float = 0.25, confidence_threshold: float = 0.5, smoothing_window: int = 3,
+                 debounce_seconds: float = 0.5, clock: Optional[Callable[[], float]] = None,
+                 max_chunk: int = 16000, preprocessor: Optional[AudioPreprocessor] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.model = model.to(self.dev).eval()
+        self.pre = preprocessor or AudioPreprocessor(sample_rate=sample_rate, segment_duration=window_duration,
+                                                     device="cuda", **SHIPPED_FLAGS)
+        self.n_streams = n_streams
+        self.window = int(sample_rate * window_duration)
+        self.hop = int(sample_rate * hop_duration)
+        self.max_chunk = max_chunk
+        self.ring_len = self.window + max_chunk + self.hop
+        self.rings = torch.zeros((n_streams, self.ring_len), dtype=torch.float32, device=self.dev)
+        self.written = np.zeros(n_streams, dtype=np.int64)       # absolute samples written per stream
+        self.next_start = np.zeros(n_streams, dtype=np.int64)    # absolute start of the next window per stream
+        self.threshold = confidence_threshold
+        self.debounce = debounce_seconds
+        self.history = [deque(maxlen=smoothing_window) for _ in range(n_streams)]
+        self.last_detection = np.zeros(n_streams, dtype=np.float64)
+        self.clock = clock or (lambda: __import__("time").time())
+        self.window_probs: List[List[float]] = [[] for _ in range(n_streams)]
+        self._lib = _lib.load()
+
+    def reset(self):
+        self.written[:] = 0
+        self.next_start[:] = 0
+        self.last_detection[:] = 0
+        for h in self.history:
+            h.clear()
+
+    def push(self, chunks, stream_ids=None) -> List[Tuple[int, float, float]]:
+        """chunks: (n, L) float32 (numpy or torch, host or device), one row per stream in ``stream_ids``
+        (default: all streams in order).  Returns [(stream, time, smoothed_confidence), ...] detections."""
+        if isinstance(chunks, np.ndarray):
+            chunks = torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32))
+        if chunks.dim() == 1:
+            chunks = chunks.unsqueeze(0)
+        n, length = chunks.shape
+        ids = np.arange(self.n_streams, dtype=np.int32) if stream_ids is None else np.asarray(stream_ids, np.int32)
+        if len(ids) != n or length > self.max_chunk:
+            raise ValueError("push: one row per stream id, chunk length <= max_chunk")
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        d_chunks = chunks.to(self.dev, torch.float32, non_blocking=True).contiguous()
+        meta = torch.from_numpy(np.concatenate([ids.astype(np.int64), self.written[ids]])).to(self.dev, non_blocking=True)
+        d_ids = meta[:n].to(torch.int32)
+        _lib.check(self._lib.cough_ring_write(self.rings.data_ptr(), self.ring_len, d_chunks.data_ptr(), length,
+                                              d_ids.data_ptr(), meta[n:].data_ptr(), n, stream), "cough_ring_write")
+        self.written[ids] += length
+
+        # every window that is complete now, stream-major then time order (the reference's while-loop)
+        w_ids, w_starts = [], []
+        for s in ids:
+            while self.written[s] - self.next_start[s] >= self.window:
+                w_ids.append(s)
+                w_starts.append(self.next_start[s])
+                self.next_start[s] += self.hop
+        if not w_ids:
+            return []
+        nw = len(w_ids)
+        wmeta = torch.from_numpy(np.concatenate([np.asarray(w_ids, np.int64), np.asarray(w_starts, np.int64)])).to(
+            self.dev, non_blocking=True)
+        wi = wmeta[:nw].to(torch.int32)
+        windows = torch.empty((nw, self.window), dtype=torch.float32, device=self.dev)
+        _lib.check(self._lib.cough_window_gather(self.rings.data_ptr(), self.ring_len, wi.data_ptr(),
+                                                 wmeta[nw:].data_ptr(), nw, self.window, windows.data_ptr(), stream),
+                   "cough_window_gather")
+        feats = self.pre.featurize_batch(windows, normalize=True)
+        _, probs = self.model.predict(feats.unsqueeze(1))
+        p = probs[:, 1].to("cpu").numpy()               # the one host sync of the tick
+
+        detections = []
+        now = self.clock()
+        fired = set()
+        for k, s in enumerate(w_ids):
+            if s in fired:                               # inference.py:239: later windows of this chunk are dropped
+                continue
+            conf = float(p[k])
+            self.window_probs[s].append(conf)
+            self.history[s].append(conf)
+            smoothed = float(np.mean(self.history[s]))
+            if smoothed >= self.threshold and now - self.last_detection[s] >= self.debounce:
+                self.last_detection[s] = now
+                detections.append((int(s), now, smoothed))
+                fired.add(s)
+        return detections

@@ -85,3 +85,38 @@ def test_ring_write_and_window_gather():
                                                out.data_ptr(), stream), "window_gather")
             want = host[[4, 0, 2], start:start + W]
             assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_multi_stream_detector_matches_per_stream_oracles():
+    from cough_detector_amd.streaming import MultiStreamDetector
+    sd = synth.random_state_dict(seed=5)
+    sd["fc.2.bias"] = sd["fc.2.bias"] + torch.tensor([0.0, 0.12])
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1)
+    model.load_state_dict(sd)
+    S = 5
+    now = {"t": 0.0}
+    det = MultiStreamDetector(model, S, confidence_threshold=0.5, smoothing_window=3, debounce_seconds=0.5,
+                              clock=lambda: now["t"])
+    refs = [oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"]) for _ in range(S)]
+    streams = np.stack([synth.make_stream(20 + s, 3.0) for s in range(S)])
+    got_events, ref_events = [], []
+    for i in range(0, streams.shape[1], 1600):
+        now["t"] = (i + 1600) / 16000.0
+        got_events.append(sorted(d[0] for d in det.push(streams[:, i:i + 1600])))
+        ref_events.append(sorted(s for s in range(S) if refs[s].process_audio_chunk(streams[s, i:i + 1600]) is not None))
+    for s in range(S):
+        assert len(det.window_probs[s]) == len(refs[s].window_probs) == 9
+        assert np.abs(np.array(det.window_probs[s]) - np.array(refs[s].window_probs)).max() < 1e-3
+    assert got_events == ref_events
+    # a long chunk that completes several windows at once (ring wrap + multi-window tick)
+    det.reset()
+    refs = [oengine.EngineOracle(sd, 2.0, 3, 0.5, clock=lambda: now["t"]) for _ in range(S)]   # threshold 2: never fires
+    det.threshold = 2.0
+    for i in range(0, 48000 - 9600 + 1, 9600):
+        det.push(streams[:, i:i + 9600])
+        for s in range(S):
+            refs[s].process_audio_chunk(streams[s, i:i + 9600])
+    for s in range(S):
+        assert len(refs[s].window_probs) > 5
+        tail = det.window_probs[s][-len(refs[s].window_probs):]
+        assert np.abs(np.array(tail) - np.array(refs[s].window_probs)).max() < 1e-3
