@@ -497,28 +497,37 @@ __device__ __forceinline__ int swz_off(int P, int j) {   // bf16 offset of 16-by
     return P * C + 8 * (j ^ ((P / PPR) & (CH - 1)));
 }
 
+#ifdef COUGH_K1_STAMPS
+// diagnostic build only (tools/rb_stamps.py): per-workgroup s_memtime at phase boundaries
+__device__ unsigned long long* g_rb_stamp_buf = nullptr;
+#define RB_STAMP(slot)                                                                        \
+    do {                                                                                      \
+        if (g_rb_stamp_buf && threadIdx.x == 0)                                               \
+            g_rb_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define RB_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int WREP = 4;   // replicas of the fragment-packed weights (L2 channel spreading)
+
 struct RbArgs {
     const bf16_t* x;      // [B][XH][XW][CIN]
     int XH, XW, OH, OW, n_clips;
-    const bf16_t* w1;     // [COUT][k1tot]  (k = tap*CIN + c, zero-padded to a multiple of 64)
-    const bf16_t* w2;     // [COUT][k2tot]  (k = tap*COUT + c, then CIN projection channels, zero-padded)
-    int k1tot, k2tot;
+    const bf16_t* wf1;    // conv1 weights as MFMA fragments [KS1][NT][64 lanes][8]: lane (r,h) of (k-step s, n-tile t)
+    const bf16_t* wf2;    //   holds W[n = 32t + r][k = 16s + 8h .. +7]; conv2 K = 9*COUT taps, then the CIN projection
     const float* b1;
     const float* b2;      // conv2 bias + projection bias
     bf16_t* out;          // [B][OH][OW][COUT]
 };
 
-template <int CIN, int COUT, int G, int MW, int NW, int WAVES>
+template <int CIN, int COUT, int G, int MW, int WAVES>
 struct RbCfg {
-    static constexpr int NT = COUT / 32, NG = NT / NW, MG = WAVES / NG, MTMAX = MG * MW;
+    static constexpr int NT = COUT / 32, MG = WAVES / NT, MTMAX = MG * MW;
     static constexpr int THREADS = WAVES * 64;
-    static constexpr int WPITCH = 72;
-    static constexpr int WPIECES = (COUT * 8 + THREADS - 1) / THREADS;   // 16-byte weight pieces per thread per chunk
+    static constexpr int KS1 = 9 * CIN / 16, KS2 = (9 * COUT + CIN) / 16;   // 16-wide MFMA k-steps
     static size_t lds_bytes(int XH, int XW, int OH, int OW) {
-        const size_t img = std::max(size_t(G) * (XH + 2) * (XW + 2) * CIN, size_t(G) * (OH + 2) * (OW + 2) * COUT) * 2;
-        const size_t skip = size_t(MTMAX) * 32 * CIN * 2;
-        const size_t wst = size_t(2) * COUT * WPITCH * 2;
-        return img + skip + wst;
+        return (size_t(G) * (XH + 2) * (XW + 2) * CIN + size_t(G) * (OH + 2) * (OW + 2) * COUT) * 2;
     }
 };
 
@@ -526,93 +535,97 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
     return make_uint2(uint32_t(f2bf(a)) | (uint32_t(f2bf(b)) << 16), uint32_t(f2bf(c)) | (uint32_t(f2bf(d)) << 16));
 }
 
-template <int CIN, int COUT, int G, int MW, int NW, int WAVES>
+// Fused residual block, v3.  One workgroup = G clips.
+//   * x is staged ONCE into a zero-bordered, XOR-swizzled LDS image; h = ReLU(conv1) goes to a second
+//     bordered LDS image and never touches HBM; the 1x1 stride-2 projection reads the centre tap of the x image.
+//   * Waves free-run: wave (mg, ng) owns MW 32-pixel tiles x one 32-channel tile.  Its weight fragments come
+//     straight from global/L2 in fragment order (1 KB coalesced per load) through an 8-deep register ring
+//     that runs ahead across the conv1 -> conv2 boundary; activation fragments are read from LDS one k-step
+//     ahead.  Only two workgroup barriers exist: after staging and between the two convolutions.
+//   * MFMA operands are swapped (weights = A, activations = B): a lane owns one pixel and 4 consecutive
+//     channels per register quad, so h and the output are written with 8-byte stores.
+template <int CIN, int COUT, int G, int MW, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
-    using Cfg = RbCfg<CIN, COUT, G, MW, NW, WAVES>;
-    constexpr int THREADS = Cfg::THREADS, WPITCH = Cfg::WPITCH, WPIECES = Cfg::WPIECES;
-    constexpr int CHI = CIN / 8, CHO = COUT / 8;
-    constexpr int K1 = 9 * CIN, K2M = 9 * COUT, K2 = K2M + CIN;
-    constexpr int N1 = (K1 + 63) / 64, N2 = (K2 + 63) / 64, NQ = N1 + N2;   // 64-wide weight chunks
+    using Cfg = RbCfg<CIN, COUT, G, MW, WAVES>;
+    constexpr int THREADS = Cfg::THREADS, NT = Cfg::NT, KS1 = Cfg::KS1, KS2 = Cfg::KS2, KS = KS1 + KS2;
+    constexpr int CHI = CIN / 8, CHO = COUT / 8, K2M = 9 * COUT;
+    constexpr int D = 16;  // weight prefetch depth (k-steps)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int XHb = a.XH + 2, XWb = a.XW + 2, OHb = a.OH + 2, OWb = a.OW + 2;
     const int per = a.OH * a.OW, M = G * per;
-    const size_t img_elems = std::max(size_t(G) * XHb * XWb * CIN, size_t(G) * OHb * OWb * COUT);
-    bf16_t* img = reinterpret_cast<bf16_t*>(smem);                  // x image, later h image
-    bf16_t* skipbuf = img + img_elems;                              // [row][CIN] swizzled by row
-    bf16_t* wst = skipbuf + size_t(Cfg::MTMAX) * 32 * CIN;          // [2][COUT][WPITCH]
+    bf16_t* ximg = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* himg = ximg + size_t(G) * XHb * XWb * CIN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int ng = wave % Cfg::NG, mg = wave / Cfg::NG;
+    const int ng = wave % NT, mg = wave / NT;
     const int clip0 = blockIdx.x * G;
+    RB_STAMP(0);
 
-    // ---- weight pipeline: chunk q -> registers (two chunks ahead) -> LDS ring stage q&1 ----------------
-    struct WRegs { uint4 v[WPIECES]; };
-    auto load_w = [&](int q) -> WRegs {
-        WRegs rg;
-        const bf16_t* src = q < N1 ? a.w1 + q * 64 : a.w2 + (q - N1) * 64;
-        const int stride = q < N1 ? N1 * 64 : N2 * 64;
-#pragma unroll
-        for (int i = 0; i < WPIECES; ++i) {
-            const int piece = tid + i * THREADS;
-            const int pc = piece < COUT * 8 ? piece : 0;   // surplus threads re-read piece 0 (never stored)
-            rg.v[i] = *reinterpret_cast<const uint4*>(src + (pc >> 3) * stride + (pc & 7) * 8);
-        }
-        return rg;
+    // ---- weight fragment stream ------------------------------------------------------------------
+    // Every workgroup walks the same weight stream, so the copies are replicated WREP times in memory and
+    // neighbouring workgroups of an XCD (blockIdx / 8) read different copies: the reads spread over L2 channels
+    // instead of all CUs hitting the same lines at the same moment.
+    const int rep = (blockIdx.x >> 3) % WREP;
+    const bf16_t* wf1 = a.wf1 + size_t(rep) * KS1 * NT * 512;
+    const bf16_t* wf2 = a.wf2 + size_t(rep) * KS2 * NT * 512;
+    auto wfrag = [&](int s) -> bf16x8 {
+        const bf16_t* p = s < KS1 ? wf1 + (size_t(s) * NT + ng) * 512 : wf2 + (size_t(s - KS1) * NT + ng) * 512;
+        return *reinterpret_cast<const bf16x8*>(p + lane * 8);
     };
-    auto store_w = [&](int buf, const WRegs rg) {
+    bf16x8 bring[D];
 #pragma unroll
-        for (int i = 0; i < WPIECES; ++i) {
-            const int piece = tid + i * THREADS;
-            if (piece < COUT * 8)
-                *reinterpret_cast<uint4*>(wst + buf * COUT * WPITCH + (piece >> 3) * WPITCH + (piece & 7) * 8) = rg.v[i];
-        }
-    };
-    WRegs w_next = load_w(0), w_next2 = load_w(NQ > 1 ? 1 : 0);
+    for (int i = 0; i < D; ++i) bring[i] = wfrag(i);
 
-    // ---- stage x: zero border, interior (swizzled), strided copy for the projection -----------------
+    // ---- stage: the x image of the G clips is one linear run of 16-byte pieces: every load is issued first,
+    // the borders of both LDS images are zeroed while the data is in flight, then the pieces are scattered to
+    // their swizzled interior cells ---------------------------------------------------------------------
     {
-        const int nborder = 2 * XWb + 2 * a.XH;   // border pixels of one clip image
-        const float inv_nb = 1.0f / float(nborder);
-        for (int i = tid; i < G * nborder * CHI; i += THREADS) {
+        const int npix = a.XH * a.XW, total = G * npix * CHI;
+        const int valid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * npix * CHI;   // pieces of real clips
+        const uint4* src = reinterpret_cast<const uint4*>(a.x + (long long)clip0 * npix * CIN);
+        constexpr int UN = 16;   // covers G*XH*XW*CIN/8 <= 16*THREADS pieces (host-checked)
+        uint4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = tid + u * THREADS;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (i < valid) v[u] = src[i];
+        }
+        const int nb_x = 2 * XWb + 2 * a.XH, nb_h = 2 * OWb + 2 * a.OH;
+        const float inv_x = 1.0f / float(nb_x), inv_h = 1.0f / float(nb_h);
+        for (int i = tid; i < G * nb_x * CHI; i += THREADS) {
             const int j = i & (CHI - 1), bi = i / CHI;
-            const int g = fdiv(bi, nborder, inv_nb), bp = bi - g * nborder;
+            const int g = fdiv(bi, nb_x, inv_x), bp = bi - g * nb_x;
             int row, col;
             if (bp < XWb) { row = 0; col = bp; }
             else if (bp < 2 * XWb) { row = XHb - 1; col = bp - XWb; }
             else { const int qq = bp - 2 * XWb; row = 1 + (qq >> 1); col = (qq & 1) ? XWb - 1 : 0; }
-            *reinterpret_cast<uint4*>(img + swz_off<CIN>((g * XHb + row) * XWb + col, j)) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(ximg + swz_off<CIN>((g * XHb + row) * XWb + col, j)) = make_uint4(0, 0, 0, 0);
         }
-        const int npix = a.XH * a.XW, total = G * npix * CHI;
+        for (int i = tid; i < G * nb_h * CHO; i += THREADS) {
+            const int j = i & (CHO - 1), bi = i / CHO;
+            const int g = fdiv(bi, nb_h, inv_h), bp = bi - g * nb_h;
+            int row, col;
+            if (bp < OWb) { row = 0; col = bp; }
+            else if (bp < 2 * OWb) { row = OHb - 1; col = bp - OWb; }
+            else { const int qq = bp - 2 * OWb; row = 1 + (qq >> 1); col = (qq & 1) ? OWb - 1 : 0; }
+            *reinterpret_cast<uint4*>(himg + swz_off<COUT>((g * OHb + row) * OWb + col, j)) = make_uint4(0, 0, 0, 0);
+        }
         const float inv_np = 1.0f / float(npix), inv_xw = 1.0f / float(a.XW);
-        const int valid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * npix * CHI;   // pieces of real clips
-        const uint4* src = reinterpret_cast<const uint4*>(a.x + (long long)clip0 * npix * CIN);
-        for (int base = tid; base < total; base += 4 * THREADS) {
-            uint4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {   // the source is one linear run of 16-byte pieces: loads first
-                const int i = base + u * THREADS;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (i < valid) v[u] = src[i];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * THREADS;
-                if (i >= total) continue;
+        for (int u = 0; u < UN; ++u) {
+            const int i = tid + u * THREADS;
+            if (i < total) {
                 const int j = i & (CHI - 1), pi_all = i / CHI;
                 const int g = fdiv(pi_all, npix, inv_np), pi = pi_all - g * npix;
                 const int y = fdiv(pi, a.XW, inv_xw), xx = pi - y * a.XW;
-                *reinterpret_cast<uint4*>(img + swz_off<CIN>((g * XHb + y + 1) * XWb + xx + 1, j)) = v[u];
-                if (!(y & 1) && !(xx & 1))   // pixel (2*oh, 2*ow) feeds the 1x1 stride-2 projection
-                    *reinterpret_cast<uint4*>(skipbuf + swz_off<CIN>(g * per + (y >> 1) * a.OW + (xx >> 1), j)) = v[u];
+                *reinterpret_cast<uint4*>(ximg + swz_off<CIN>((g * XHb + y + 1) * XWb + xx + 1, j)) = v[u];
             }
         }
     }
-    store_w(0, w_next);
-    w_next = w_next2;
-    __syncthreads();
 
     // ---- per-lane geometry: lane r owns output pixel R of each of its M-tiles ---------------------------
-    int pr1[MW][3], pr2[MW][3], hs_skip[MW], off_skip[MW], p_h[MW];
+    int pr1[MW][3], pr2[MW][3];
     const float inv_per = 1.0f / float(per), inv_ow = 1.0f / float(a.OW);
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
@@ -625,127 +638,123 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
             pr1[mt][kh] = (g * XHb + 2 * oh + kh) * XWb + 2 * ow;   // x-image pixel of tap (kh, 0)
             pr2[mt][kh] = (g * OHb + oh + kh) * OWb + ow;           // h-image pixel of tap (kh, 0)
         }
-        p_h[mt] = pr2[mt][1] + 1;                                    // h-image pixel of the output itself
-        hs_skip[mt] = h ^ ((Rc / (16 / CHI)) & (CHI - 1));
-        off_skip[mt] = Rc * CIN;
     }
-    const bool active = (mg * MW) * 32 < M;   // waves whose tiles lie beyond M only help with weights / barriers
+    const bool active = (mg * MW) * 32 < M;   // waves whose tiles all lie beyond M only take part in barriers
+    RB_STAMP(1);
+    __syncthreads();
+    RB_STAMP(2);
 
-    // accumulators: operands are swapped (weights = MFMA A, activations = MFMA B), so lane r holds pixel r
-    // and register (reg&3) + 8*(reg>>2) + 4*h is the channel: 4 consecutive channels per register quad
-    f32x16 acc[MW][NW];
+    f32x16 acc[MW];
 #pragma unroll
-    for (int mt = 0; mt < MW; ++mt)
+    for (int mt = 0; mt < MW; ++mt) acc[mt] = f32x16{0};
+
+    // Activation fragments of k-step s (compile-time at every call site).  The pixel-dependent part of the
+    // swizzled LDS address -- base pointer of the tap's pixel and hs = h ^ swizzle(pixel) -- is computed once
+    // per (tile, tap) when the first k-step of a tap is fetched; every further k-step of that tap costs one
+    // xor and one shift-add per fragment.
+    const bf16_t* tbase[MW];
+    int ths[MW];
+    auto afrag1 = [&](auto sc, int mt) -> bf16x8 {
+        constexpr int s = decltype(sc)::value;
+        constexpr bool conv1 = s < KS1;
+        constexpr int kg = conv1 ? s * 16 : (s - KS1) * 16;
+        constexpr bool proj = !conv1 && kg >= K2M;
+        constexpr int C = (conv1 || proj) ? CIN : COUT, CH = C / 8;
+        constexpr int kt = proj ? kg - K2M : kg;                 // k inside this operand
+        constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
+        if constexpr (c16 == 0) {                                // first k-step of a tap: new pixel
+            const int P = ((conv1 || proj) ? pr1[mt][kh] : pr2[mt][kh]) + kw;
+            ths[mt] = h ^ ((P / (16 / CH)) & (CH - 1));
+            tbase[mt] = ((conv1 || proj) ? ximg : himg) + P * C;
+        }
+        return *reinterpret_cast<const bf16x8*>(tbase[mt] + 8 * ((2 * c16) ^ ths[mt]));
+    };
+    auto afrags = [&](auto sc, bf16x8 (&dst)[MW]) {
 #pragma unroll
-        for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = f32x16{0};
+        for (int mt = 0; mt < MW; ++mt) dst[mt] = afrag1(sc, mt);
+    };
 
-    const bf16_t* lb_lane = wst + (ng * NW * 32 + r) * WPITCH + 8 * h;
+    bf16x8 af[2][MW];
+    if (active) afrags(std::integral_constant<int, 0>{}, af[0]);
 
-    // One step per 64-wide weight chunk; Q is a compile-time constant so taps / channel offsets fold away.
-    auto step = [&]<int q>() {
-        if constexpr (q == N1) {
-            // ---- h = ReLU(conv1 + b1) -> bordered h image over the (now dead) x image -------------------
-            const int nborder = 2 * OWb + 2 * a.OH;
-            const float inv_nb = 1.0f / float(nborder);
-            for (int i = tid; i < G * nborder * CHO; i += THREADS) {
-                const int j = i & (CHO - 1), bi = i / CHO;
-                const int g = fdiv(bi, nborder, inv_nb), bp = bi - g * nborder;
-                int row, col;
-                if (bp < OWb) { row = 0; col = bp; }
-                else if (bp < 2 * OWb) { row = OHb - 1; col = bp - OWb; }
-                else { const int qq = bp - 2 * OWb; row = 1 + (qq >> 1); col = (qq & 1) ? OWb - 1 : 0; }
-                *reinterpret_cast<uint4*>(img + swz_off<COUT>((g * OHb + row) * OWb + col, j)) = make_uint4(0, 0, 0, 0);
-            }
+    auto step = [&]<int s>() {
+        if constexpr (s == KS1) {
+            RB_STAMP(3);
+            // ---- h = ReLU(conv1 + b1) -> interior of the h image (its border was zeroed while staging) ----
             if (active) {
 #pragma unroll
                 for (int mt = 0; mt < MW; ++mt) {
                     const bool rok = (mg * MW + mt) * 32 + r < M;
+                    const int P = pr2[mt][1] + 1;
 #pragma unroll
-                    for (int nt = 0; nt < NW; ++nt)
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const int n0 = (ng * NW + nt) * 32 + 8 * gq + 4 * h;
-                            const float4 bb = *reinterpret_cast<const float4*>(a.b1 + n0);
-                            const uint2 pk = pack4_bf16(fmaxf(acc[mt][nt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][nt][4 * gq + 1] + bb.y, 0.f),
-                                                        fmaxf(acc[mt][nt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][nt][4 * gq + 3] + bb.w, 0.f));
-                            if (rok) *reinterpret_cast<uint2*>(img + swz_off<COUT>(p_h[mt], n0 >> 3) + (n0 & 7)) = pk;
-                        }
-#pragma unroll
-                    for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = f32x16{0};
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int n0 = ng * 32 + 8 * gq + 4 * h;
+                        const float4 bb = *reinterpret_cast<const float4*>(a.b1 + n0);
+                        const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
+                                                    fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
+                        if (rok) *reinterpret_cast<uint2*>(himg + swz_off<COUT>(P, n0 >> 3) + (n0 & 7)) = pk;
+                    }
+                    acc[mt] = f32x16{0};
                 }
             }
             __syncthreads();
+            RB_STAMP(4);
+            if (active) afrags(std::integral_constant<int, s>{}, af[s & 1]);
         }
-        const WRegs w_load = load_w(q + 2 < NQ ? q + 2 : q);
         if (active) {
-            const bf16_t* lb = lb_lane + (q & 1) * COUT * WPITCH;
-            auto kstep = [&]<int ks>() {
-                constexpr int kg = (q < N1 ? q : q - N1) * 64 + ks * 16;
-                if constexpr ((q < N1 && kg >= K1) || (q >= N1 && kg >= K2)) return;   // zero-padded tail of K
-                bf16x8 af[MW], bfr[NW];
-                if constexpr (q < N1) {
-                    constexpr int tap = kg / CIN, c16 = (kg % CIN) / 16, kh = tap / 3, kw = tap % 3;
+            // Software pipeline, pinned with scheduling barriers: ahead of MFMA mt of this step sit the address
+            // math + ds_read of the NEXT step's fragment mt (and, once per step, the weight load D steps ahead).
+            // Each pair issues in the ~24 cycles an MFMA leaves free; left alone, the scheduler sinks every
+            // ds_read next to its MFMA (ds_read -> lgkmcnt(0) -> mfma) and each MFMA pays the full LDS latency.
+            const bf16x8 bw = bring[s % D];
 #pragma unroll
-                    for (int mt = 0; mt < MW; ++mt) {
-                        const int P = pr1[mt][kh] + kw;
-                        const int hs = h ^ ((P / (16 / CHI)) & (CHI - 1));
-                        af[mt] = *reinterpret_cast<const bf16x8*>(img + P * CIN + 8 * ((2 * c16) ^ hs));
-                    }
-                } else if constexpr (kg < K2M) {
-                    constexpr int tap = kg / COUT, c16 = (kg % COUT) / 16, kh = tap / 3, kw = tap % 3;
-#pragma unroll
-                    for (int mt = 0; mt < MW; ++mt) {
-                        const int P = pr2[mt][kh] + kw;
-                        const int hs = h ^ ((P / (16 / CHO)) & (CHO - 1));
-                        af[mt] = *reinterpret_cast<const bf16x8*>(img + P * COUT + 8 * ((2 * c16) ^ hs));
-                    }
-                } else {
-                    constexpr int c16 = (kg - K2M) / 16;
-#pragma unroll
-                    for (int mt = 0; mt < MW; ++mt)
-                        af[mt] = *reinterpret_cast<const bf16x8*>(skipbuf + off_skip[mt] + 8 * ((2 * c16) ^ hs_skip[mt]));
+            for (int mt = 0; mt < MW; ++mt) {
+                if constexpr (s + 1 < KS && s + 1 != KS1)
+                    af[(s + 1) & 1][mt] = afrag1(std::integral_constant<int, s + 1>{}, mt);
+                if constexpr (s + D < KS) {
+                    if (mt == 0) bring[s % D] = wfrag(s + D);
                 }
-#pragma unroll
-                for (int nt = 0; nt < NW; ++nt)
-                    bfr[nt] = *reinterpret_cast<const bf16x8*>(lb + nt * 32 * WPITCH + ks * 16);
-#pragma unroll
-                for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NW; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
-            };
-            kstep.template operator()<0>();
-            kstep.template operator()<1>();
-            kstep.template operator()<2>();
-            kstep.template operator()<3>();
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, af[s & 1][mt], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if constexpr (q + 1 < NQ) store_w((q + 1) & 1, w_next);
-        __syncthreads();
-        w_next = w_load;
     };
-    [&]<int... Qs>(std::integer_sequence<int, Qs...>) {
-        (step.template operator()<Qs>(), ...);
-    }(std::make_integer_sequence<int, NQ>{});
+    [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+        (step.template operator()<Ss>(), ...);
+    }(std::make_integer_sequence<int, KS>{});
 
-    // ---- epilogue: out = ReLU(conv2 + projection + b2), 8-byte stores of 4 consecutive channels ---------
+    RB_STAMP(5);
+    // ---- epilogue: out = ReLU(conv2 + projection + b2).  The accumulators go to a bf16 [pixel][COUT] tile in
+    // LDS (over the dead x image; rows padded by 16 B), then the workgroup copies the tile -- which is one
+    // contiguous run of NHWC output -- to global with 16-byte-per-lane coalesced stores. ----------------------
+    constexpr int OPITCH = COUT + 8;   // bf16 elements per LDS row
+    __syncthreads();                   // every wave is done reading the x / h images
+    bf16_t* otile = ximg;
     if (active) {
-        bf16_t* o = a.out + (long long)clip0 * per * COUT;
-        const int mvalid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * per;
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
             const int R = (mg * MW + mt) * 32 + r;
 #pragma unroll
-            for (int nt = 0; nt < NW; ++nt)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int n0 = (ng * NW + nt) * 32 + 8 * gq + 4 * h;
-                    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
-                    const uint2 pk = pack4_bf16(fmaxf(acc[mt][nt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][nt][4 * gq + 1] + bb.y, 0.f),
-                                                fmaxf(acc[mt][nt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][nt][4 * gq + 3] + bb.w, 0.f));
-                    if (R < mvalid) *reinterpret_cast<uint2*>(o + (long long)R * COUT + n0) = pk;
-                }
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n0 = ng * 32 + 8 * gq + 4 * h;
+                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
+                const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
+                                            fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
+                *reinterpret_cast<uint2*>(otile + R * OPITCH + n0) = pk;
+            }
         }
     }
+    __syncthreads();
+    {
+        const int mvalid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * per;
+        uint4* o = reinterpret_cast<uint4*>(a.out + (long long)clip0 * per * COUT);
+        for (int p = tid; p < mvalid * CHO; p += THREADS) {
+            const int row = p / CHO, ch = p - row * CHO;
+            o[p] = *reinterpret_cast<const uint4*>(otile + row * OPITCH + ch * 8);
+        }
+    }
+    RB_STAMP(6);
 }
 
 template <typename T>
@@ -852,6 +861,7 @@ struct cough_resnet {
     cough::bf16_t* d_stem_wfrag;   // bf16 mode: [4 steps][2 halves][32 n][8 taps] MFMA B fragments
     float* d_stem_b;       // [32]
     void* d_w[4];          // packed [N][Ktot]: b0.conv1, b0.conv2+skip, b1.conv1, b1.conv2+skip
+    cough::bf16_t* d_wfrag[4];   // bf16 mode: the same weights as MFMA fragments [K/16][N/32][64][8] (fused block kernels)
     float* d_b[4];
     int ktot[4];
     float* d_fcw;          // [2][128]
@@ -884,6 +894,18 @@ int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const Folde
         std::vector<bf16_t> wb(w.size());
         for (size_t i = 0; i < w.size(); ++i) wb[i] = f2bf_host(w[i]);
         if (int e = upload(&m->d_w[slot], wb)) return e;
+        // fragment order for the fused block kernels: lane (r, h) of (k-step s, n-tile t) holds W[32t + r][16s + 8h ..+7]
+        const int Kr = Km + Ks, ks = Kr / 16, nt = N / 32;
+        std::vector<bf16_t> wf(size_t(ks) * nt * 512 * WREP);
+        for (int st = 0; st < ks; ++st)
+            for (int t = 0; t < nt; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 8; ++jj)
+                        wf[((size_t(st) * nt + t) * 64 + lane) * 8 + jj] =
+                            wb[size_t(32 * t + (lane & 31)) * K + 16 * st + 8 * (lane >> 5) + jj];
+        for (int rp = 1; rp < WREP; ++rp)
+            std::copy(wf.begin(), wf.begin() + size_t(ks) * nt * 512, wf.begin() + size_t(rp) * ks * nt * 512);
+        if (int e = upload(reinterpret_cast<void**>(&m->d_wfrag[slot]), wf)) return e;
     }
     return upload(reinterpret_cast<void**>(&m->d_b[slot]), b);
 }
@@ -954,22 +976,24 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
         if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
-            using Cfg0 = RbCfg<32, 64, 2, 1, 2, 9>;
-            using Cfg1 = RbCfg<64, 128, 4, 3, 1, 8>;
+            using Cfg0 = RbCfg<32, 64, 2, 3, 6>;     // block 0: 2 clips, 6 waves = 3 pixel-tile groups x 2 channel tiles
+            using Cfg1 = RbCfg<64, 128, 3, 4, 4>;    // block 1: 3 clips, 4 waves = all 4 pixel tiles x 4 channel tiles
             RbArgs ra{};
             ra.x = reinterpret_cast<const bf16_t*>(k.x); ra.XH = k.xh; ra.XW = k.xw; ra.OH = k.oh; ra.OW = k.ow;
             ra.n_clips = n;
-            ra.w1 = reinterpret_cast<const bf16_t*>(m->d_w[k.s1]); ra.k1tot = m->ktot[k.s1]; ra.b1 = m->d_b[k.s1];
-            ra.w2 = reinterpret_cast<const bf16_t*>(m->d_w[k.s2]); ra.k2tot = m->ktot[k.s2]; ra.b2 = m->d_b[k.s2];
+            ra.wf1 = m->d_wfrag[k.s1]; ra.b1 = m->d_b[k.s1];
+            ra.wf2 = m->d_wfrag[k.s2]; ra.b2 = m->d_b[k.s2];
             ra.out = reinterpret_cast<bf16_t*>(k.out);
             const size_t lds = i == 0 ? Cfg0::lds_bytes(k.xh, k.xw, k.oh, k.ow) : Cfg1::lds_bytes(k.xh, k.xw, k.oh, k.ow);
-            const int g = i == 0 ? 2 : 4, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
-            if (m->dtype == COUGH_DTYPE_BF16 && lds <= 160 * 1024 && g * k.oh * k.ow <= mtmax * 32) {
+            const int g = i == 0 ? 2 : 3, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
+            const int threads = i == 0 ? Cfg0::THREADS : Cfg1::THREADS;
+            if (m->dtype == COUGH_DTYPE_BF16 && lds <= 160 * 1024 && g * k.oh * k.ow <= mtmax * 32 &&
+                g * k.xh * k.xw * (k.cin / 8) <= 16 * threads) {
                 const dim3 grid((unsigned)((n + g - 1) / g));
                 if (i == 0)
-                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 2, 1, 2, 9>), grid, dim3(Cfg0::THREADS), lds, st, ra);
+                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 2, 3, 6>), grid, dim3(Cfg0::THREADS), lds, st, ra);
                 else
-                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 4, 3, 1, 8>), grid, dim3(Cfg1::THREADS), lds, st, ra);
+                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 4, 4>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
                 continue;
             }
@@ -999,6 +1023,12 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
 
 }  // namespace
 }  // namespace cough
+
+#ifdef COUGH_K1_STAMPS
+extern "C" int cough_debug_set_rb_stamp_buffer(void* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_rb_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype) {
     using namespace cough;
@@ -1052,10 +1082,10 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_fcb), fb);
     }
     if (!err && dtype == COUGH_DTYPE_BF16) {   // the fused block kernels use more than 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 2, 1, 2, 9>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 2, 3, 6>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 4, 3, 1, 8>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 4, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("cough_resnet_create: %s", hipGetErrorString(e));
@@ -1076,6 +1106,7 @@ extern "C" void cough_resnet_destroy(cough_resnet* m) {
     (void)hipFree(m->d_stem_wfrag);
     (void)hipFree(m->d_stem_b);
     for (int i = 0; i < 4; ++i) {
+        (void)hipFree(m->d_wfrag[i]);
         (void)hipFree(m->d_w[i]);
         (void)hipFree(m->d_b[i]);
     }
