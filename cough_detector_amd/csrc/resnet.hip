@@ -519,6 +519,12 @@ struct RbArgs {
     const float* b1;
     const float* b2;      // conv2 bias + projection bias
     bf16_t* out;          // [B][OH][OW][COUT]
+    // optional fused head (block 1 only; fcw == nullptr: none): global mean over OHxOW -> Linear(COUT, 2)
+    const float* fcw;     // [2][COUT]
+    const float* fcb;     // [2]
+    float* logits;        // [B][2]
+    float* probs;         // [B][2] or nullptr
+    int* preds;           // [B] or nullptr
 };
 
 template <int CIN, int COUT, int G, int MW, int WAVES>
@@ -754,6 +760,43 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
             o[p] = *reinterpret_cast<const uint4*>(otile + row * OPITCH + ch * 8);
         }
     }
+    if constexpr (COUT == 128 && THREADS % 128 == 0) {
+        // ---- fused head (model.py:242-247, :257-265): the block output tile is still in LDS, so the global
+        // mean, Linear(128, 2), softmax and argmax of the workgroup's clips finish here (same summation order
+        // as tail_kernel: pixels in order, then lanes of a wave, then the two waves of a clip) ------------
+        if (a.fcw != nullptr) {
+            float* hred = reinterpret_cast<float*>(otile + Cfg::MTMAX * 32 * OPITCH);   // [THREADS/64][2]
+            const int c = tid & 127;
+            for (int g0 = 0; g0 < G; g0 += THREADS / 128) {
+                const int g = g0 + (tid >> 7);
+                float l0 = 0.f, l1 = 0.f;
+                if (g < G) {
+                    float sum = 0.f;
+                    for (int i = 0; i < per; ++i) sum += bf2f(otile[(g * per + i) * OPITCH + c]);
+                    const float mean = sum / float(per);
+                    l0 = wave_sum(mean * a.fcw[c]);
+                    l1 = wave_sum(mean * a.fcw[128 + c]);
+                }
+                __syncthreads();
+                if (lane == 0) { hred[wave * 2] = l0; hred[wave * 2 + 1] = l1; }
+                __syncthreads();
+                if (g < G && c == 0 && clip0 + g < a.n_clips) {
+                    const int w0 = (tid >> 7) * 2;   // the clip's two waves
+                    l0 = hred[w0 * 2] + hred[(w0 + 1) * 2] + a.fcb[0];
+                    l1 = hred[w0 * 2 + 1] + hred[(w0 + 1) * 2 + 1] + a.fcb[1];
+                    const long long b = clip0 + g;
+                    a.logits[b * 2] = l0;
+                    a.logits[b * 2 + 1] = l1;
+                    if (a.probs) {
+                        const float mx = fmaxf(l0, l1), e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.0f / (e0 + e1);
+                        a.probs[b * 2] = e0 * inv;
+                        a.probs[b * 2 + 1] = e1 * inv;
+                    }
+                    if (a.preds) a.preds[b] = (l1 > l0) ? 1 : 0;
+                }
+            }
+        }
+    }
     RB_STAMP(6);
 }
 
@@ -973,6 +1016,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     struct Blk { char *x, *h, *out; int xh, xw, oh, ow, cin, cout, s1, s2; };
     const Blk blk[2] = {{w.a1, w.h0, w.a2, s.P1h, s.P1w, s.B0h, s.B0w, 32, 64, 0, 1},
                         {w.a2, w.h1, w.a3, s.B0h, s.B0w, s.B1h, s.B1w, 64, 128, 2, 3}};
+    bool head_done = false;   // the fused block-1 kernel also runs the head
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
         if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
@@ -984,6 +1028,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
             ra.wf1 = m->d_wfrag[k.s1]; ra.b1 = m->d_b[k.s1];
             ra.wf2 = m->d_wfrag[k.s2]; ra.b2 = m->d_b[k.s2];
             ra.out = reinterpret_cast<bf16_t*>(k.out);
+            if (i == 1) { ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds; }
             const size_t lds = i == 0 ? Cfg0::lds_bytes(k.xh, k.xw, k.oh, k.ow) : Cfg1::lds_bytes(k.xh, k.xw, k.oh, k.ow);
             const int g = i == 0 ? 2 : 3, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
             const int threads = i == 0 ? Cfg0::THREADS : Cfg1::THREADS;
@@ -995,6 +1040,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                 else
                     hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 4, 4>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
+                if (i == 1) head_done = true;
                 continue;
             }
         }
@@ -1015,9 +1061,11 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
         c2.M = (long long)n * k.oh * k.ow;
         if (int e = launch_conv<T>(m, c2, st)) return e;
     }
-    hipLaunchKernelGGL(tail_kernel<T>, dim3(n), dim3(128), 0, st, reinterpret_cast<const T*>(w.a3), s.B1h * s.B1w,
-                       m->d_fcw, m->d_fcb, d_logits, d_probs, d_preds);
-    COUGH_HIP_CHECK(hipGetLastError());
+    if (!head_done) {
+        hipLaunchKernelGGL(tail_kernel<T>, dim3(n), dim3(128), 0, st, reinterpret_cast<const T*>(w.a3), s.B1h * s.B1w,
+                           m->d_fcw, m->d_fcb, d_logits, d_probs, d_preds);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
     return COUGH_OK;
 }
 
