@@ -26,18 +26,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_CLIP = 64000 + 36360          # waveform read + (90,101) f32 written
+BYTES_PER_CLIP = 64000 + 36360          # featurise: waveform read + (90,101) f32 written
+BYTES_PER_CLIP_FUSED = 64000 + 35200    # featurise + bf16 stem fused: waveform read + (22,25,32) bf16 written
 FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
+FLOP_PER_CLIP_NO_STEM = 35668480        # minus the stem's 32*45*51*49 MAC (it runs inside the featurise kernel)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
 
-def measured_traffic(batch: int):
+def measured_traffic(batch: int, fused: bool = False):
     """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (tools/pmc_k1.sh ->
     tools/pmc_to_json.py; FETCH_SIZE doubled per the gfx950 calibration).  PMC cannot be collected from
     inside this process, so the figure is read from profiles/ and only used when the batch matches."""
-    path = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_k1_fused_pmc.json" if fused else "r01_k1_pmc.json")
     try:
         with open(path) as f:
             p = json.load(f)
@@ -136,19 +138,26 @@ def main():
     model.load_state_dict(synth.random_state_dict(seed=3))
     model.to(dev).eval()
     feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
+    pipe = cda.CoughPipeline(pre, model)
+    fused = args.dtype == "bf16" and not args.featurize_only   # the stem runs inside the featurise kernel
     gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
 
+    for e3 in ev:            # create the underlying HIP events (the library re-records them around K1)
+        for e in e3:
+            e.record()
+
     def step(i, timed):
-        if timed:
-            ev[i][0].record()
-        pre.featurize_batch(wav, normalize=True, out=feats)
-        if timed:
-            ev[i][1].record()
         if args.featurize_only:
+            if timed:
+                ev[i][0].record()
+            pre.featurize_batch(wav, normalize=True, out=feats)
+            if timed:
+                ev[i][1].record()
             return None
-        logits = model(feats.unsqueeze(1))
+        # one C-ABI call: featurise (+ stem) -> residual blocks -> head; features are not materialised
+        logits = pipe(wav, normalize=True, events=(ev[i][0], ev[i][1]) if timed else None)
         if timed:
             ev[i][2].record()
         if world > 1:
@@ -179,8 +188,9 @@ def main():
 
     if rank == 0:
         total_clips = world * B * K
-        achieved = B * BYTES_PER_CLIP / (k1_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(B)
+        k1_bytes = BYTES_PER_CLIP_FUSED if fused else BYTES_PER_CLIP
+        achieved = B * k1_bytes / (k1_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(B, fused)
         line = {
             "metric": "1s@16kHz clips/sec (featurise+infer)" if not args.featurize_only
                       else "1s@16kHz clips/sec (featurise only)",
@@ -196,15 +206,17 @@ def main():
                        "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
                        "collective": "all_gather(logits) per step" if world > 1 else "none",
                        "weights": "random-init, BN stats randomised"},
-            "roofline": {"kernel": "featurize_kernel (K1)", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "featurize_kernel<stem fused> (K1+K2)" if fused else "featurize_kernel (K1)",
+                         "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": round(k1_ms, 4),
-                         "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP},
+                         "algorithmic_bytes_per_launch": B * k1_bytes},
         }
         if not args.featurize_only:
-            tf = B * FLOP_PER_CLIP / (net_ms * 1e-3) / 1e12
+            tf = B * (FLOP_PER_CLIP_NO_STEM if fused else FLOP_PER_CLIP) / (net_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            line["roofline_classifier"] = {"kernel": "stem+conv_mfma x4+tail (K2-K5)", "bound": "mfma",
+            line["roofline_classifier"] = {"kernel": "residual blocks + head (K3-K5)" + ("" if fused else " + stem (K2)"),
+                                           "bound": "mfma",
                                            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                            "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4)}
         if world == 1 and args.cpu_seconds > 0:

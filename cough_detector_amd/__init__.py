@@ -4,6 +4,7 @@ hand-written HIP kernels (``csrc/``) reached through the C-ABI in ``include/coug
 from .preprocessing import AudioPreprocessor, RealtimePreprocessor, create_preprocessor
 from .model import CoughDetectorResidual, ResidualBlock, create_model, count_parameters
 from .inference import CoughDetectorInference
+from .pipeline import CoughPipeline
 
 __all__ = ["AudioPreprocessor", "RealtimePreprocessor", "create_preprocessor", "CoughDetectorResidual",
-           "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference"]
+           "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference", "CoughPipeline"]

@@ -30,7 +30,10 @@
 #include <cstring>
 #include <vector>
 
+#include <hip/hip_bf16.h>
+
 #include "common.h"
+#include "internal.h"
 
 namespace cough {
 namespace {
@@ -155,10 +158,24 @@ __device__ constexpr float W32S[8] = {0.0f, -0.19509032201612825f, -0.3826834323
                                       -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f,
                                       -0.98078528040323043f};
 
-template <bool PRE_EMPH>   // pre-emphasis is a separate instantiation: it never costs the shipped path registers
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<uint16_t*>(&b);
+}
+// geometry of the fused stem for the 90x101 feature image (resnet.hip: stem_bf16_kernel / stem_lds)
+constexpr int ST_H = 90, ST_W = NFRAMES, ST_P1H = 22, ST_P1W = 25, ST_ROWS = 94, ST_PITCH = 106;
+constexpr int ST_PER = ST_P1H * ST_P1W, ST_TILES = (ST_PER + 7) / 8;
+static_assert(size_t(ST_ROWS) * ST_PITCH * 2 <= LDS_MEL, "the bf16 feature image aliases the dB buffer");
+
+// PRE_EMPH: pre-emphasis is a separate instantiation (it never costs the shipped path registers).
+// STEM: the classifier's bf16 stem (conv7x7 s2 + BN + ReLU + maxpool, model.py:227-232) runs at the end of
+// the kernel out of a bf16 copy of the feature image in LDS; `out` may then be nullptr.
+template <bool PRE_EMPH, bool STEM>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
-    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta) {
+    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta, StemFuse stem) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);
     float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const long long clip = blockIdx.x;
     const float* x = wav + clip * wav_stride;
     float* o = out + clip * (long long)nfeat * NFRAMES;
+    const bool wr = out != nullptr;   // features are materialised (always, unless the fused pipeline asks not to)
 
     K1_STAMP(0);
     K1_STAMP(1);
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         float2 v;
         v.x = fminf(fmaxf((d.x + 80.0f) * 0.0125f, 0.f), 1.f);       // (dB + 80) / 80, preprocessing.py:409-410
         v.y = fminf(fmaxf((d.y + 80.0f) * 0.0125f, 0.f), 1.f);       // (x * 1/80 is within 1 ulp of x / 80)
-        reinterpret_cast<float2*>(o)[i2] = v;
+        if (wr) reinterpret_cast<float2*>(o)[i2] = v;
     }
     __syncthreads();
     K1_STAMP(4);   // mel rows written
@@ -368,15 +386,45 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
     }
     __syncthreads();
+    uint16_t* img = reinterpret_cast<uint16_t*>(melbuf);   // STEM: bf16 feature image, row = f + 3, col = t + 3
+    if constexpr (STEM) {
+        // the floored dB values move to registers, then the dB buffer becomes the zero-bordered bf16 image
+        float2 dv[(NMEL * NFRAMES / 2 + THREADS - 1) / THREADS];
+#pragma unroll
+        for (int it = 0; it < (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS; ++it) {
+            const int i2 = tid + it * THREADS;
+            dv[it] = i2 < NMEL * NFRAMES / 2 ? reinterpret_cast<const float2*>(melbuf)[i2] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        for (int i = tid; i < ST_ROWS * ST_PITCH / 8; i += THREADS) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = (ST_ROWS * ST_PITCH / 8) * 8 + tid; i < ST_ROWS * ST_PITCH; i += THREADS) img[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS; ++it) {
+            const int e = 2 * (tid + it * THREADS);
+            if (e < NMEL * NFRAMES) {
+                const int m0 = e / NFRAMES, t0 = e - m0 * NFRAMES;
+                const int m1 = t0 + 1 < NFRAMES ? m0 : m0 + 1, t1 = t0 + 1 < NFRAMES ? t0 + 1 : 0;
+                img[(m0 + 3) * ST_PITCH + t0 + 3] = f2bf(fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f));
+                img[(m1 + 3) * ST_PITCH + t1 + 3] = f2bf(fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f));
+            }
+        }
+    }
     float* o_mfcc = o + NMEL * NFRAMES;
     float* o_delta = o_mfcc + NMF;
     for (int item = tid; item < NMF; item += THREADS) {
         const int c = item / NFRAMES, t = item - c * NFRAMES;
         const float* row = mf + c * NFRAMES;
         const float d = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;   // :353-355
-        o_mfcc[item] = row[t];
-        o_delta[item] = d;
+        if (wr) {
+            o_mfcc[item] = row[t];
+            o_delta[item] = d;
+        }
         if (delta_delta) dl[item] = d;
+        if constexpr (STEM) {
+            img[(NMEL + c + 3) * ST_PITCH + t + 3] = f2bf(row[t]);
+            img[(NMEL + NMFCC + c + 3) * ST_PITCH + t + 3] = f2bf(d);
+        }
     }
     K1_STAMP(6);
     if (delta_delta) {
@@ -386,6 +434,42 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             const int c = item / NFRAMES, t = item - c * NFRAMES;
             const float* row = dl + c * NFRAMES;
             o_dd[item] = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
+        }
+    }
+    if constexpr (STEM) {
+        // ---- K2 fused: conv7x7 s2 p3 (1->32) + BN + ReLU + maxpool2 on v_mfma_f32_32x32x16_bf16.  K is 8 kernel
+        // rows x 8 taps (7 + a zero tap; row 8 all zero): MFMA step st, lane half h <-> kernel row 2*st+h,
+        // 8 consecutive image pixels per lane = 4 aligned ds_read_b32.  GEMM rows are (pool window, dy, dx), so
+        // the 2x2 max is a max over 4 accumulator registers of one lane. ------------------------------------
+        __syncthreads();
+        const int sr = lane & 31, sh = lane >> 5;
+        bf16x8 bw[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) bw[st] = *reinterpret_cast<const bf16x8*>(stem.wfrag + ((st * 2 + sh) * 32 + sr) * 8);
+        const float bn = stem.bias[sr];
+        const int q = sr >> 2, dy = (sr >> 1) & 1, dx = sr & 1;
+        uint16_t* oa = stem.a1 + clip * (long long)ST_PER * 32;
+        for (int tile = wave; tile < ST_TILES; tile += WAVES) {
+            int P = tile * 8 + q;
+            if (P >= ST_PER) P = ST_PER - 1;
+            const int ph = P / ST_P1W, pw = P - ph * ST_P1W;
+            const uint32_t* base =
+                reinterpret_cast<const uint32_t*>(img + (2 * (2 * ph + dy) + sh) * ST_PITCH + 2 * (2 * pw + dx));
+            f32x16 acc2 = {0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint32_t* p = base + st * ST_PITCH;   // +2 image rows per step = ST_PITCH dwords
+                union { uint32_t u[4]; bf16x8 v; } a;
+                a.u[0] = p[0]; a.u[1] = p[1]; a.u[2] = p[2]; a.u[3] = p[3];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[st], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int Po = tile * 8 + 2 * g + sh;
+                float v = fmaxf(fmaxf(acc2[4 * g], acc2[4 * g + 1]), fmaxf(acc2[4 * g + 2], acc2[4 * g + 3])) + bn;
+                v = fmaxf(v, 0.f);
+                if (Po < ST_PER) oa[Po * 32 + sr] = f2bf(v);
+            }
         }
     }
 }
@@ -472,23 +556,37 @@ extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
 extern "C" int cough_featurizer_num_features(const cough_featurizer* f) { return f ? f->nfeat : -1; }
 extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return f ? cough::NFRAMES : -1; }
 
-extern "C" int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
-                               float* d_feat, int n_clips, int flags, void* stream) {
-    using namespace cough;
-    COUGH_REQUIRE(f && d_wav && d_feat, COUGH_EINVAL, "cough_featurize: NULL argument");
+namespace cough {
+int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
+
+int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
+                     int flags, const StemFuse* stem, hipStream_t stream) {
+    COUGH_REQUIRE(f && d_wav && (d_feat || stem), COUGH_EINVAL, "cough_featurize: NULL argument");
     COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0");
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
+    COUGH_REQUIRE(!stem || (f->nfeat == ST_H && !f->cfg.use_pre_emphasis), COUGH_EUNSUPPORTED,
+                  "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
-    if (f->cfg.use_pre_emphasis)
-        hipLaunchKernelGGL(featurize_kernel<true>, dim3(n_clips), dim3(THREADS), LDS_TOTAL,
-                           static_cast<hipStream_t>(stream), d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
-                           f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta);
+    const dim3 grid(n_clips), block(THREADS);
+    const StemFuse none{nullptr, nullptr, nullptr};
+    if (stem)
+        hipLaunchKernelGGL((featurize_kernel<false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, *stem);
+    else if (f->cfg.use_pre_emphasis)
+        hipLaunchKernelGGL((featurize_kernel<true, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, none);
     else
-        hipLaunchKernelGGL(featurize_kernel<false>, dim3(n_clips), dim3(THREADS), LDS_TOTAL,
-                           static_cast<hipStream_t>(stream), d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
-                           f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta);
+        hipLaunchKernelGGL((featurize_kernel<false, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, none);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
+}
+}  // namespace cough
+
+extern "C" int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
+                               float* d_feat, int n_clips, int flags, void* stream) {
+    COUGH_REQUIRE(d_feat, COUGH_EINVAL, "cough_featurize: NULL argument");
+    return cough::launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, nullptr, static_cast<hipStream_t>(stream));
 }

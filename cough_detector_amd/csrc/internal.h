@@ -1,0 +1,24 @@
+// Cross-translation-unit plumbing of libcough_amd (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+struct cough_featurizer;
+struct cough_resnet;
+
+namespace cough {
+
+// bf16 stem (K2) executed at the end of the featurise kernel: the 90x101 feature image never leaves the CU.
+struct StemFuse {
+    const uint16_t* wfrag;   // [4 steps][2 halves][32 channels][8 taps] MFMA fragments (resnet.hip)
+    const float* bias;       // [32]
+    uint16_t* a1;            // [n][22][25][32] bf16 NHWC
+};
+
+// featurize.hip: d_feat may be nullptr when `stem` is given (features not materialised)
+int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
+                     int flags, const StemFuse* stem, hipStream_t stream);
+int featurizer_num_features(const cough_featurizer* f);
+
+}  // namespace cough

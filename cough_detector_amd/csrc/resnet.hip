@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal.h"
 
 #define COUGH_DTYPE_DIRECT 2
 
@@ -992,10 +993,12 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes& s, float* d_logits, float* d_probs,
-                 int* d_preds, char* ws, hipStream_t st) {
+                 int* d_preds, char* ws, hipStream_t st, bool stem_done = false) {
     const Workspace w = carve(m, ws, n, s);
     const long long n_pool = (long long)n * s.P1h * s.P1w;
-    if (m->dtype == COUGH_DTYPE_DIRECT) {
+    if (stem_done) {
+        // a1 was produced by the featurise kernel (cough_pipeline_forward)
+    } else if (m->dtype == COUGH_DTYPE_DIRECT) {
         hipLaunchKernelGGL(stem_direct_kernel<T>, dim3((unsigned)((n_pool * 32 + 255) / 256)), dim3(256), 0, st, d_feat,
                            s.H, s.W, s.P1h, s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
     } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
@@ -1211,4 +1214,53 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
                            reinterpret_cast<const bf16_t*>(src), d_out, C, HW, total);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused pipeline
+namespace cough {
+namespace {
+bool can_fuse_stem(const cough_featurizer* f, const cough_resnet* m) {
+    return m->dtype == COUGH_DTYPE_BF16 && featurizer_num_features(f) == 90 && cough_featurizer_num_frames(f) == 101;
+}
+}  // namespace
+}  // namespace cough
+
+extern "C" size_t cough_pipeline_workspace_bytes(const cough_featurizer* f, const cough_resnet* m, int n_clips) {
+    using namespace cough;
+    if (!f || !m || n_clips < 0) return 0;
+    const int H = featurizer_num_features(f), W = cough_featurizer_num_frames(f);
+    size_t b = cough_resnet_workspace_bytes(m, n_clips, H, W);
+    if (!can_fuse_stem(f, m)) b += align256(size_t(n_clips) * H * W * sizeof(float));   // feature scratch
+    return b;
+}
+
+extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_resnet* m, const float* d_wav,
+                                      long long wav_stride, int n_clips, int flags, float* d_feat, float* d_logits,
+                                      float* d_probs, int* d_preds, void* d_workspace, size_t workspace_bytes,
+                                      void* stream, void* ev_featurize_begin, void* ev_featurize_end) {
+    using namespace cough;
+    COUGH_REQUIRE(f && m && d_wav && d_logits && d_workspace, COUGH_EINVAL, "cough_pipeline_forward: NULL argument");
+    COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_pipeline_forward: n_clips < 0");
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL,
+                  "cough_pipeline_forward: workspace must be 256-byte aligned");
+    COUGH_REQUIRE(workspace_bytes >= cough_pipeline_workspace_bytes(f, m, n_clips), COUGH_EWORKSPACE,
+                  "cough_pipeline_forward: workspace too small");
+    if (n_clips == 0) return COUGH_OK;
+    const int H = featurizer_num_features(f), W = cough_featurizer_num_frames(f);
+    const Shapes s = make_shapes(H, W);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(d_workspace);
+    if (ev_featurize_begin) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_begin), st));
+    if (can_fuse_stem(f, m)) {
+        const Workspace w = carve(m, ws, n_clips, s);
+        const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<uint16_t*>(w.a1)};
+        if (int e = launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st)) return e;
+        if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
+        return forward_impl<bf16_t>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
+    }
+    float* feat = d_feat ? d_feat : reinterpret_cast<float*>(ws + cough_resnet_workspace_bytes(m, n_clips, H, W));
+    if (int e = launch_featurize(f, d_wav, wav_stride, feat, n_clips, flags, nullptr, st)) return e;
+    if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
+    if (m->esize == 4) return forward_impl<float>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
+    return forward_impl<bf16_t>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
 }

@@ -106,7 +106,7 @@ typedef struct cough_resnet_weights {
 } cough_resnet_weights;
 
 #define COUGH_DTYPE_FP32 0 /* exact-f32 MFMA (v_mfma_f32_*_f32): CPU-reference numerics */
-#define COUGH_DTYPE_BF16 1 /* bf16 operands, f32 accumulate (stem stays f32) */
+#define COUGH_DTYPE_BF16 1 /* bf16 operands and activations, f32 accumulate */
 
 typedef struct cough_resnet cough_resnet;
 
@@ -125,6 +125,20 @@ int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips
  * LAST forward on this workspace to d_out as [n_clips][C][H][W] float32. */
 int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips,
                                  int height, int width, int which, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------ fused pipeline (K1 -> K5)
+ * waveform -> logits in one call: what CoughDetectorInference.process_audio_chunk does per window with
+ * preprocessor.add_audio (/root/reference/src/inference.py:214) followed by predict (:217, :165-189), for a
+ * whole batch.  With a bf16 classifier and the shipped 90x101 layout the stem runs inside the featurise kernel
+ * and the feature image never leaves the CU; d_feat (nullable) additionally materialises the features
+ * [n_clips][num_features][num_frames].  flags: COUGH_FEAT_NORMALIZE.  Results equal cough_featurize followed
+ * by cough_resnet_forward.  The two optional events are recorded on `stream` around the featurise launch
+ * (profiling hook; hipEventRecord only, no synchronisation). */
+size_t cough_pipeline_workspace_bytes(const cough_featurizer* f, const cough_resnet* m, int n_clips);
+int cough_pipeline_forward(const cough_featurizer* f, const cough_resnet* m, const float* d_wav,
+                           long long wav_stride, int n_clips, int flags, float* d_feat, float* d_logits,
+                           float* d_probs, int* d_preds, void* d_workspace, size_t workspace_bytes, void* stream,
+                           void* ev_featurize_begin, void* ev_featurize_end /* optional hipEvent_t, may be NULL */);
 
 /* ------------------------------------------------------------------ streaming windows (K6)
  * Device-side counterpart of RealtimePreprocessor.add_audio's FIFO

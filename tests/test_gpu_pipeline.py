@@ -1,0 +1,55 @@
+"""Fused pipeline (cough_pipeline_forward) vs the two-step path and the CPU oracle."""
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from cough_detector_amd import synth
+from oracle import featurizer as ofeat, resnet as ores
+from parity import FEAT_TOL, LOGIT_TOL, SHIPPED, feature_errors, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_pipeline_equals_two_step(resnet_golden, dtype, normalize):
+    sd, _ = resnet_golden
+    w = synth_batch(700, 37, peak_normalize=False).cuda() * 0.4          # 37: ragged last clip groups (G = 2, 3)
+    w[3] = 0.0
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
+    model.load_state_dict(sd)
+    model.cuda()
+    pipe = cda.CoughPipeline(pre, model)
+    feats = pre.featurize_batch(w, normalize=normalize)
+    want = model(feats.unsqueeze(1))
+    got = pipe(w, normalize=normalize)
+    assert torch.equal(got, want)                                        # same kernels' arithmetic, fused or not
+    got2, f2 = pipe(w, normalize=normalize, return_features=True)
+    assert torch.equal(got2, want) and torch.equal(f2, feats)
+    preds, probs = pipe.predict(w, normalize=normalize)
+    assert torch.equal(preds, want.argmax(1))
+    assert (probs - torch.softmax(want, 1)).abs().max() < 1e-6
+    assert pipe(w[:0]).shape == (0, 2)
+
+
+def test_pipeline_full_batch_against_oracle(resnet_golden):
+    sd, _ = resnet_golden
+    B = 4096
+    w = synth_batch(9000, B, peak_normalize=False)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+    model.load_state_dict(sd)
+    pipe = cda.CoughPipeline(pre, model.cuda())
+    logits = pipe(w.cuda(), normalize=True)
+    assert torch.equal(pipe(w.cuda()[:64], normalize=True), logits[:64])  # batch invariance
+    sample = torch.arange(0, B, 32)
+    ref = ores.forward(ofeat.extract_features_batch(w[sample], normalize_first=True).unsqueeze(1), sd)
+    err = (logits[sample].cpu() - ref).abs().max().item()
+    print(f"pipeline bf16 B=4096 sample: logits max abs err {err:.2e}")
+    assert err < LOGIT_TOL
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record(); ev[1].record()
+    pipe(w.cuda(), events=ev)
+    torch.cuda.synchronize()
+    assert 0.0 < ev[0].elapsed_time(ev[1]) < 50.0
