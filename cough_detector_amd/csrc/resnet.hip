@@ -1023,7 +1023,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
         if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
-            using Cfg0 = RbCfg<32, 64, 2, 3, 6>;     // block 0: 2 clips, 6 waves = 3 pixel-tile groups x 2 channel tiles
+            using Cfg0 = RbCfg<32, 64, 1, 3, 4>;     // block 0: 1 clip (66 KB LDS: two workgroups per CU), 4 waves = 2 tile groups x 2 channel tiles
             using Cfg1 = RbCfg<64, 128, 3, 4, 4>;    // block 1: 3 clips, 4 waves = all 4 pixel tiles x 4 channel tiles
             RbArgs ra{};
             ra.x = reinterpret_cast<const bf16_t*>(k.x); ra.XH = k.xh; ra.XW = k.xw; ra.OH = k.oh; ra.OW = k.ow;
@@ -1033,13 +1033,13 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
             ra.out = reinterpret_cast<bf16_t*>(k.out);
             if (i == 1) { ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds; }
             const size_t lds = i == 0 ? Cfg0::lds_bytes(k.xh, k.xw, k.oh, k.ow) : Cfg1::lds_bytes(k.xh, k.xw, k.oh, k.ow);
-            const int g = i == 0 ? 2 : 3, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
+            const int g = i == 0 ? 1 : 3, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
             const int threads = i == 0 ? Cfg0::THREADS : Cfg1::THREADS;
             if (m->dtype == COUGH_DTYPE_BF16 && lds <= 160 * 1024 && g * k.oh * k.ow <= mtmax * 32 &&
                 g * k.xh * k.xw * (k.cin / 8) <= 16 * threads) {
                 const dim3 grid((unsigned)((n + g - 1) / g));
                 if (i == 0)
-                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 2, 3, 6>), grid, dim3(Cfg0::THREADS), lds, st, ra);
+                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 1, 3, 4>), grid, dim3(Cfg0::THREADS), lds, st, ra);
                 else
                     hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 4, 4>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
@@ -1133,7 +1133,7 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_fcb), fb);
     }
     if (!err && dtype == COUGH_DTYPE_BF16) {   // the fused block kernels use more than 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 2, 3, 6>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 1, 3, 4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 4, 4>),
