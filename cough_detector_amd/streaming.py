@@ -8,7 +8,8 @@ every ``hop`` samples (``/root/reference/src/preprocessing.py:597-610``) and
 * samples live in device ring buffers (K6 ``cough_ring_write``); the host keeps only two absolute sample
   counters per stream (written, next window start);
 * each ``push`` assembles every window that just completed, over all streams, with ONE
-  ``cough_window_gather``, ONE featurise launch (normalisation fused) and ONE classifier forward;
+  ``cough_window_gather`` and ONE ``cough_pipeline_forward`` (featurise with fused normalisation and stem,
+  residual blocks, head);
 * the only host<->device traffic per tick is the chunk upload and one (n_windows,) probability download;
 * smoothing (deque mean), threshold, debounce and the "drop the rest of this chunk's windows after a
   detection" rule are the reference's, per stream, on an injectable clock.
@@ -22,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .pipeline import CoughPipeline
 from .preprocessing import AudioPreprocessor
 
 SHIPPED_FLAGS = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
@@ -38,6 +40,7 @@ class MultiStreamDetector:
         self.model = model.to(self.dev).eval()
         self.pre = preprocessor or AudioPreprocessor(sample_rate=sample_rate, segment_duration=window_duration,
                                                      device="cuda", **SHIPPED_FLAGS)
+        self.pipe = CoughPipeline(self.pre, self.model)   # windows -> probabilities in one C-ABI call
         self.n_streams = n_streams
         self.window = int(sample_rate * window_duration)
         self.hop = int(sample_rate * hop_duration)
@@ -97,8 +100,7 @@ class MultiStreamDetector:
         _lib.check(self._lib.cough_window_gather(self.rings.data_ptr(), self.ring_len, wi.data_ptr(),
                                                  wmeta[nw:].data_ptr(), nw, self.window, windows.data_ptr(), stream),
                    "cough_window_gather")
-        feats = self.pre.featurize_batch(windows, normalize=True)
-        _, probs = self.model.predict(feats.unsqueeze(1))
+        _, probs = self.pipe.predict(windows, normalize=True)
         p = probs[:, 1].to("cpu").numpy()               # the one host sync of the tick
 
         detections = []
