@@ -31,7 +31,8 @@ SYMBOLS = (
 class FeatConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("n_fft", C.c_int), ("hop_length", C.c_int), ("win_length", C.c_int),
                 ("n_mels", C.c_int), ("n_mfcc", C.c_int), ("segment_samples", C.c_int),
-                ("use_pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float), ("use_delta_delta", C.c_int)]
+                ("use_pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float), ("use_delta_delta", C.c_int),
+                ("use_pcen", C.c_int)]
 
 
 _FP = C.POINTER(C.c_float)

@@ -175,7 +175,7 @@ static_assert(size_t(ST_ROWS) * ST_PITCH * 2 <= LDS_MEL, "the bf16 feature image
 template <bool PRE_EMPH, bool STEM>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
-    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta, StemFuse stem) {
+    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta, int pcen, StemFuse stem) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);
     float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
@@ -338,6 +338,37 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // AmplitudeToDB('power', top_db=80): amin = 1e-10 <=> -100 dB; the floor is relative to the per-clip max
     const float floor_db = fmaxf(raw_max - shift, -100.0f) - 80.0f;
     K1_STAMP(3);   // all waves finished P1
+    bool wr_mel = wr;
+    if (pcen) {
+        // PCEN branch of extract_mel_spectrogram (preprocessing.py:305-340, :400-404): mel rows =
+        // min-max-normalised (mel / (1e-6 + smooth)^0.98 + 2)^0.5 - 2^0.5, smooth = 10-frame moving average
+        // (zero padded, always / 10).  Works on the (peak-normalised) mel POWER, rebuilt from the raw dB
+        // buffer; thread = (band, quarter of the frames) slides the window over its own 36 powers.
+        const int m = tid >> 2, t0 = (tid & 3) * 26, t1 = t0 + 26 < NFRAMES ? t0 + 26 : NFRAMES;
+        float p[36], pv[26];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            const int u = t0 - 5 + k;
+            p[k] = (u >= 0 && u < NFRAMES) ? exp2f((melbuf[m * NFRAMES + u] - shift) * 0.33219280948873623f) : 0.f;
+        }
+        float lmin = INFINITY, lmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 26; ++k) {
+            float sm = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) sm += p[k + q];
+            pv[k] = sqrtf(p[k + 5] / __powf(1e-6f + sm * 0.1f, 0.98f) + 2.0f) - 1.41421356237309515f;
+            if (t0 + k < t1) { lmin = fminf(lmin, pv[k]); lmax = fmaxf(lmax, pv[k]); }
+        }
+        const float mn = -block_max(-lmin, red, tid), mx = block_max(lmax, red, tid);
+        const float rng = 1.0f / (mx - mn + 1e-8f);
+        if (wr) {
+#pragma unroll
+            for (int k = 0; k < 26; ++k)
+                if (t0 + k < t1) o[m * NFRAMES + t0 + k] = (pv[k] - mn) * rng;
+        }
+        wr_mel = false;   // the log-mel pass below only prepares the floored dB for the MFCC branch
+    }
     for (int i2 = tid; i2 < NMEL * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores
         float2 d = reinterpret_cast<float2*>(melbuf)[i2];
         d.x = fmaxf(fmaxf(d.x - shift, -100.0f), floor_db);
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         float2 v;
         v.x = fminf(fmaxf((d.x + 80.0f) * 0.0125f, 0.f), 1.f);       // (dB + 80) / 80, preprocessing.py:409-410
         v.y = fminf(fmaxf((d.y + 80.0f) * 0.0125f, 0.f), 1.f);       // (x * 1/80 is within 1 ulp of x / 80)
-        if (wr) reinterpret_cast<float2*>(o)[i2] = v;
+        if (wr_mel) reinterpret_cast<float2*>(o)[i2] = v;
     }
     __syncthreads();
     K1_STAMP(4);   // mel rows written
@@ -558,6 +589,9 @@ extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return f
 
 namespace cough {
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
+bool featurizer_stem_fusable(const cough_featurizer* f) {
+    return f->nfeat == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+}
 
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
                      int flags, const StemFuse* stem, hipStream_t stream) {
@@ -565,7 +599,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0");
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
-    COUGH_REQUIRE(!stem || (f->nfeat == ST_H && !f->cfg.use_pre_emphasis), COUGH_EUNSUPPORTED,
+    COUGH_REQUIRE(!stem || featurizer_stem_fusable(f), COUGH_EUNSUPPORTED,
                   "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
@@ -573,13 +607,13 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const StemFuse none{nullptr, nullptr, nullptr};
     if (stem)
         hipLaunchKernelGGL((featurize_kernel<false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, *stem);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, 0, *stem);
     else if (f->cfg.use_pre_emphasis)
         hipLaunchKernelGGL((featurize_kernel<true, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, f->cfg.use_pcen, none);
     else
         hipLaunchKernelGGL((featurize_kernel<false, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, f->cfg.use_pcen, none);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }

@@ -20,5 +20,6 @@ struct StemFuse {
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
                      int flags, const StemFuse* stem, hipStream_t stream);
 int featurizer_num_features(const cough_featurizer* f);
+bool featurizer_stem_fusable(const cough_featurizer* f);   // shipped 90-row layout, no pre-emphasis, no PCEN
 
 }  // namespace cough

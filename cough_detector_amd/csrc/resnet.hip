@@ -1220,7 +1220,7 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
 namespace cough {
 namespace {
 bool can_fuse_stem(const cough_featurizer* f, const cough_resnet* m) {
-    return m->dtype == COUGH_DTYPE_BF16 && featurizer_num_features(f) == 90 && cough_featurizer_num_frames(f) == 101;
+    return m->dtype == COUGH_DTYPE_BF16 && featurizer_stem_fusable(f) && cough_featurizer_num_frames(f) == 101;
 }
 }  // namespace
 }  // namespace cough

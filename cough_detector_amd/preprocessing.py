@@ -74,8 +74,6 @@ class AudioPreprocessor:
         self.device = device
 
         unsupported = []
-        if use_pcen:
-            unsupported.append("use_pcen=True")
         if use_spectral_contrast:
             unsupported.append("use_spectral_contrast=True")
         if not use_mfcc:
@@ -84,7 +82,8 @@ class AudioPreprocessor:
             raise ValueError(
                 "AudioPreprocessor: " + ", ".join(unsupported) + " is not implemented on the MI355X path; the "
                 "shipped configuration (src/train.py:264-287) is use_mfcc=True, use_pcen=False, "
-                "use_spectral_contrast=False")
+                "use_spectral_contrast=False (the reference's spectral-contrast rows are NaN by construction: its "
+                "first band is a single bin whose top-20% slice is empty)")
         if (sample_rate, n_fft, hop_length, win_length, n_mels, n_mfcc, self.segment_samples) != \
                 (16000, 512, 160, 400, 64, 13, 16000):
             raise ValueError("AudioPreprocessor: the MI355X path implements sample_rate=16000, n_fft=512, "
@@ -103,7 +102,8 @@ class AudioPreprocessor:
             _cuda_device()
             cfg = _lib.FeatConfig(self.sample_rate, self.n_fft, self.hop_length, self.win_length, self.n_mels,
                                   self.n_mfcc, self.segment_samples, int(bool(self.use_pre_emphasis)),
-                                  float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)))
+                                  float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)),
+                                  int(bool(self.use_pcen)))
             h = C.c_void_p()
             _lib.check(lib.cough_featurizer_create(C.byref(h), C.byref(cfg), _lib.fptr(self._window),
                                                    _lib.fptr(self._mel_fb), _lib.fptr(self._dct)),

@@ -57,6 +57,7 @@ typedef struct cough_feat_config {
     int use_pre_emphasis;  /* preprocessing.py:214-240 */
     float pre_emphasis_coef;
     int use_delta_delta;   /* preprocessing.py:471-474 */
+    int use_pcen;          /* preprocessing.py:305-340, :400-404: mel rows = min-max normalised PCEN instead of log-mel */
 } cough_feat_config;
 
 typedef struct cough_featurizer cough_featurizer;

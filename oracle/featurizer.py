@@ -3,7 +3,8 @@
 Restates ``/root/reference/src/preprocessing.py`` for the configuration the
 reference ships (``/root/reference/src/train.py:264-287``): log-mel(64) +
 MFCC(13) + delta-MFCC(13) -> (1, 90, 101), plus the two cheap optional flags
-(pre-emphasis, delta-delta).  PCEN and spectral contrast are not restated.
+(pre-emphasis, delta-delta) and the PCEN branch.  Spectral contrast is not restated
+(the reference's rows are NaN by construction).
 
 PARITY UNPINNED against torchaudio: the reference delegates STFT / mel / dB /
 DCT to ``torchaudio.transforms`` (``preprocessing.py:94-127``), which is not
@@ -152,8 +153,21 @@ def pad_or_trim(waveform: torch.Tensor, length: int = SAMPLE_RATE) -> torch.Tens
     return torch.nn.functional.pad(waveform, (left, padding - left))
 
 
-def extract_mel_spectrogram(waveform: torch.Tensor, fb=None) -> torch.Tensor:
-    """F1-F4 -- preprocessing.py:387-412, non-PCEN branch."""
+def apply_pcen(mel_spec: torch.Tensor, alpha: float = 0.98, delta: float = 2.0, r: float = 0.5,
+               eps: float = 1e-6) -> torch.Tensor:
+    """preprocessing.py:305-340: moving average over 10 frames (zero padded, count_include_pad), then
+    (mel / (eps + smooth)^alpha + delta)^r - delta^r."""
+    smooth = torch.nn.functional.avg_pool2d(mel_spec.unsqueeze(0), kernel_size=(1, 10), stride=(1, 1),
+                                            padding=(0, 5)).squeeze(0)
+    smooth = smooth[:, :, :mel_spec.shape[2]]
+    return (mel_spec / (eps + smooth).pow(alpha) + delta).pow(r) - delta ** r
+
+
+def extract_mel_spectrogram(waveform: torch.Tensor, fb=None, use_pcen: bool = False) -> torch.Tensor:
+    """F1-F4 -- preprocessing.py:387-412 (PCEN branch :400-404, log branch :405-410)."""
+    if use_pcen:
+        m = apply_pcen(mel_spectrogram(waveform, fb))
+        return (m - m.min()) / (m.max() - m.min() + 1e-8)
     mel_db = amplitude_to_db(mel_spectrogram(waveform, fb))
     return ((mel_db + 80) / 80).clamp(0, 1)
 
@@ -165,10 +179,10 @@ def extract_mfcc(waveform: torch.Tensor, fb=None, dct=None) -> torch.Tensor:
 
 
 def extract_features(waveform: torch.Tensor, use_pre_emphasis: bool = False, pre_emphasis_coef: float = 0.97,
-                     use_delta_delta: bool = False, fb=None, dct=None) -> torch.Tensor:
+                     use_delta_delta: bool = False, use_pcen: bool = False, fb=None, dct=None) -> torch.Tensor:
     """F8 -- preprocessing.py:432-489: (1, N) -> (1, 90 [or 103], T)."""
     w = pre_emphasis(waveform, pre_emphasis_coef) if use_pre_emphasis else waveform
-    mel = extract_mel_spectrogram(w, fb)
+    mel = extract_mel_spectrogram(w, fb, use_pcen)
     mfcc = extract_mfcc(w, fb, dct)
     delta = compute_deltas(mfcc)
     feats = [mel, mfcc, delta]

@@ -138,3 +138,21 @@ def test_full_size_batch_properties(pre):
     zz = f[:, 64:77]
     zp = torch.cat([zz[:, :, :1], zz, zz[:, :, -1:]], dim=2)
     assert torch.equal((zp[:, :, 2:] - zp[:, :, :-2]) / 2, f[:, 77:90])
+
+
+def test_pcen_branch():
+    """8f 'next' row: use_pcen=True (a constructor default of the reference), mel rows = min-max PCEN."""
+    w = synth_batch(400, 16)
+    raw = synth_batch(500, 8, peak_normalize=False) * 0.3
+    flags = {**SHIPPED, "use_pcen": True}
+    p = cda.AudioPreprocessor(device="cuda", **flags)
+    f = p.extract_features(w.cuda())
+    ref = ofeat.extract_features_batch(w, use_pcen=True)
+    mel, rel = feature_errors(f, ref)
+    print(f"pcen: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+    assert f[:, :64].min() >= 0 and f[:, :64].max() <= 1
+    got = p.featurize_batch(raw.cuda(), normalize=True)
+    ref = ofeat.extract_features_batch(raw, normalize_first=True, use_pcen=True)
+    mel, rel = feature_errors(got, ref)
+    assert mel < FEAT_TOL and rel < FEAT_TOL

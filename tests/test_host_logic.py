@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_ctypes_structs_match_header_layout():
-    assert ctypes.sizeof(_lib.FeatConfig) == 10 * 4
+    assert ctypes.sizeof(_lib.FeatConfig) == 11 * 4
     assert ctypes.sizeof(_lib.ConvBN) == 6 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_lib.ResNetWeights) == (7 * 6 + 2) * 8 + 8
 
@@ -52,8 +52,9 @@ def test_preprocessor_interface_and_errors():
     p = cda.AudioPreprocessor(**SHIPPED)
     assert p.get_num_features() == 90 and p.get_expected_time_frames() == 101
     assert cda.AudioPreprocessor(**{**SHIPPED, "use_delta_delta": True}).get_num_features() == 103
-    with pytest.raises(ValueError, match="use_pcen"):
-        cda.AudioPreprocessor()                              # reference defaults include PCEN + contrast
+    with pytest.raises(ValueError, match="use_spectral_contrast"):
+        cda.AudioPreprocessor()                              # reference defaults include spectral contrast
+    assert cda.AudioPreprocessor(use_spectral_contrast=False, use_delta_delta=False).get_num_features() == 90   # PCEN on
     with pytest.raises(ValueError, match="n_fft"):
         cda.AudioPreprocessor(n_fft=1024, **SHIPPED)
     with pytest.raises(ValueError, match="16000"):
