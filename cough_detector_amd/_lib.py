@@ -24,7 +24,7 @@ SYMBOLS = (
     "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
-    "cough_ring_write", "cough_window_gather",
+    "cough_resample", "cough_ring_write", "cough_window_gather",
 )
 
 
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
         lib.cough_pipeline_workspace_bytes.argtypes = [vp, vp, i]
         lib.cough_pipeline_workspace_bytes.restype = C.c_size_t
         lib.cough_pipeline_forward.argtypes = [vp, vp, vp, ll, i, i, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+        lib.cough_resample.argtypes = [vp, ll, i, i, vp, i, i, i, vp, ll, i, vp]
         lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
         lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]
         if lib.cough_amd_abi_version() != 1:

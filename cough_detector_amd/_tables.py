@@ -38,3 +38,23 @@ def dct_matrix(n_mfcc: int, n_mels: int) -> torch.Tensor:
     dct[0] *= 1.0 / math.sqrt(2.0)
     dct *= math.sqrt(2.0 / float(n_mels))
     return dct.t().contiguous()
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Polyphase windowed-sinc kernel of ``T.Resample(orig_freq, new_freq)`` (sinc_interp_hann, the reference
+    constructs it with defaults at ``/root/reference/src/preprocessing.py:146-153``): (new, 2*width + orig)
+    float32 computed in float64 as torchaudio does, plus ``width``.  Frequencies are reduced by their gcd."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t *= base_freq
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels *= window * scale
+    return kernels.to(torch.float32).reshape(new, 2 * width + orig).contiguous(), width, orig, new

@@ -27,8 +27,42 @@ __global__ void window_gather_kernel(const float* __restrict__ rings, int ring_l
     out[(long long)w * window_len + i] = rings[(long long)ids[w] * ring_len + p];
 }
 
+// Polyphase windowed-sinc resampler: one thread per output sample; consecutive lanes = consecutive phases of
+// the same input block, so the input reads are broadcasts and the kernel rows stream from L2.
+__global__ void resample_kernel(const float* __restrict__ in, long long in_stride, int in_len,
+                                const float* __restrict__ kern, int orig, int nw, int width,
+                                float* __restrict__ out, long long out_stride, int out_len) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= out_len) return;
+    const float* x = in + (long long)blockIdx.y * in_stride;
+    const int blk = n / nw, ph = n - blk * nw, K = 2 * width + orig;
+    const float* kr = kern + (long long)ph * K;
+    const int base = blk * orig - width;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int i = base + k;
+        if (i >= 0 && i < in_len) acc = fmaf(x[i], kr[k], acc);
+    }
+    out[(long long)blockIdx.y * out_stride + n] = acc;
+}
+
 }  // namespace
 }  // namespace cough
+
+extern "C" int cough_resample(const float* d_in, long long in_stride, int n_rows, int in_len, const float* d_kernel,
+                              int orig, int new_freq, int width, float* d_out, long long out_stride, int out_len,
+                              void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_in && d_kernel && d_out, COUGH_EINVAL, "cough_resample: NULL argument");
+    COUGH_REQUIRE(n_rows >= 0 && n_rows <= 65535 && in_len >= 0 && out_len >= 0 && orig > 0 && new_freq > 0 && width > 0,
+                  COUGH_EINVAL, "cough_resample: bad sizes");
+    if (n_rows == 0 || out_len == 0) return COUGH_OK;
+    hipLaunchKernelGGL(resample_kernel, dim3((out_len + 255) / 256, n_rows), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_in, in_stride, in_len, d_kernel, orig, new_freq, width, d_out,
+                       out_stride, out_len);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
 
 extern "C" int cough_ring_write(float* d_rings, int ring_len, const float* d_chunks, int chunk_len,
                                 const int* d_stream_ids, const long long* d_write_pos, int n_chunks, void* stream) {

@@ -94,6 +94,7 @@ class AudioPreprocessor:
         self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
         self._dct = _tables.dct_matrix(n_mfcc, n_mels)
         self._handle: Optional[C.c_void_p] = None
+        self._resamplers = {}
 
     # ------------------------------------------------------------------ native handle
     def _native(self) -> C.c_void_p:
@@ -125,10 +126,26 @@ class AudioPreprocessor:
                          "decode to a float32 tensor and call process()")
 
     def resample(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
+        """T.Resample(orig_sr, sample_rate) on the GPU (``cough_resample``); (C, N) -> (C, ceil(N*sr/orig_sr))."""
         if orig_sr == self.sample_rate:
             return waveform
-        raise ValueError(f"resample: {orig_sr} Hz -> {self.sample_rate} Hz is not implemented on the MI355X path; "
-                         "resample before calling process()")
+        import math
+        dev = _cuda_device()
+        if orig_sr not in self._resamplers:          # kernel table cached per source rate, like the reference (:144-153)
+            kern, width, orig, new = _tables.sinc_resample_kernel(orig_sr, self.sample_rate)
+            self._resamplers[orig_sr] = (kern.to(dev), width, orig, new)
+        kern, width, orig, new = self._resamplers[orig_sr]
+        x = waveform.to(device=dev, dtype=torch.float32).contiguous()
+        if x.dim() != 2:
+            raise ValueError(f"resample: expected (channels, samples), got {tuple(x.shape)}")
+        rows, n = x.shape
+        out_len = int(math.ceil(new * n / orig))
+        out = torch.empty((rows, out_len), dtype=torch.float32, device=dev)
+        if rows and out_len:
+            _lib.check(_lib.load().cough_resample(x.data_ptr(), n, rows, n, kern.data_ptr(), orig, new, width,
+                                                  out.data_ptr(), out_len, out_len,
+                                                  torch.cuda.current_stream(dev).cuda_stream), "cough_resample")
+        return out
 
     def to_mono(self, waveform: torch.Tensor) -> torch.Tensor:
         if waveform.shape[0] == 1:

@@ -141,6 +141,16 @@ int cough_pipeline_forward(const cough_featurizer* f, const cough_resnet* m, con
                            float* d_probs, int* d_preds, void* d_workspace, size_t workspace_bytes, void* stream,
                            void* ev_featurize_begin, void* ev_featurize_end /* optional hipEvent_t, may be NULL */);
 
+/* ------------------------------------------------------------------ resampler (front of process())
+ * Replaces T.Resample(orig, 16000)(waveform) (/root/reference/src/preprocessing.py:146-183): polyphase
+ * windowed-sinc FIR.  d_kernel: device [new][K] float32, K = 2*width + orig, built by the caller the way
+ * torchaudio builds it (orig/new already divided by their gcd).  Row r of the input (in_len samples at
+ * d_in + r*in_stride) yields out_len = ceil(new*in_len/orig) samples at d_out + r*out_stride:
+ * out[n] = sum_k x[(n / new)*orig + k - width] * kernel[n % new][k], x = 0 outside [0, in_len). */
+int cough_resample(const float* d_in, long long in_stride, int n_rows, int in_len, const float* d_kernel,
+                   int orig, int new_freq, int width, float* d_out, long long out_stride, int out_len,
+                   void* stream);
+
 /* ------------------------------------------------------------------ streaming windows (K6)
  * Device-side counterpart of RealtimePreprocessor.add_audio's FIFO
  * (/root/reference/src/preprocessing.py:582-616) for many concurrent streams: each stream owns

@@ -153,6 +153,50 @@ def pad_or_trim(waveform: torch.Tensor, length: int = SAMPLE_RATE) -> torch.Tens
     return torch.nn.functional.pad(waveform, (left, padding - left))
 
 
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """torchaudio.functional.resample's kernel (sinc_interp_hann), built in float64 and cast to float32."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t *= base_freq
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels *= window * (base_freq / orig)
+    return kernels.to(torch.float32), width, orig, new
+
+
+def resample(waveform: torch.Tensor, orig_freq: int, new_freq: int = SAMPLE_RATE) -> torch.Tensor:
+    """T.Resample(orig_freq, new_freq)(waveform) -- preprocessing.py:146-183: zero-pad (width, width + orig),
+    conv1d with the (new, 1, K) kernel at stride orig, interleave the phases, cut to ceil(new * N / orig)."""
+    if orig_freq == new_freq:
+        return waveform
+    kernel, width, orig, new = sinc_resample_kernel(orig_freq, new_freq)
+    shape = waveform.shape
+    w = waveform.reshape(-1, shape[-1])
+    length = w.shape[1]
+    w = torch.nn.functional.pad(w, (width, width + orig))
+    res = torch.nn.functional.conv1d(w[:, None], kernel, stride=orig)
+    res = res.transpose(1, 2).reshape(w.shape[0], -1)
+    target = int(math.ceil(new * length / orig))
+    return res[..., :target].reshape(shape[:-1] + (target,))
+
+
+def to_mono(waveform: torch.Tensor) -> torch.Tensor:
+    """preprocessing.py:185-197."""
+    return waveform if waveform.shape[0] == 1 else waveform.mean(dim=0, keepdim=True)
+
+
+def process(waveform: torch.Tensor, orig_sr: int, **feature_kw) -> torch.Tensor:
+    """preprocessing.py:491-517: resample -> mono -> normalize -> pad/trim -> extract_features."""
+    w = pad_or_trim(normalize(to_mono(resample(waveform, orig_sr))))
+    return extract_features(w, **feature_kw)
+
+
 def apply_pcen(mel_spec: torch.Tensor, alpha: float = 0.98, delta: float = 2.0, r: float = 0.5,
                eps: float = 1e-6) -> torch.Tensor:
     """preprocessing.py:305-340: moving average over 10 frames (zero padded, count_include_pad), then

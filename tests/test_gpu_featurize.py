@@ -156,3 +156,24 @@ def test_pcen_branch():
     ref = ofeat.extract_features_batch(raw, normalize_first=True, use_pcen=True)
     mel, rel = feature_errors(got, ref)
     assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+@pytest.mark.parametrize("orig_sr,channels,seconds", [(44100, 2, 1.3), (22050, 1, 0.5), (48000, 1, 1.0), (8000, 2, 1.7)])
+def test_process_front_end_resample_mono_normalize_pad(orig_sr, channels, seconds):
+    """8f 'next' row: process() = resample -> mono -> normalize -> pad/trim -> features (preprocessing.py:491-517)."""
+    g = torch.Generator().manual_seed(orig_sr + channels)
+    n = int(orig_sr * seconds)
+    t = torch.arange(n) / orig_sr
+    w = torch.stack([0.3 * torch.sin(2 * torch.pi * (300 + 250 * c) * t) + 0.05 * torch.randn(n, generator=g)
+                     for c in range(channels)])
+    p = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    r = p.resample(w, orig_sr)
+    r_ref = ofeat.resample(w, orig_sr)
+    assert r.shape == r_ref.shape
+    assert (r.cpu() - r_ref).abs().max() < 2e-6
+    f = p.process(w, orig_sr)
+    ref = ofeat.process(w, orig_sr)
+    assert f.shape == ref.shape == (1, 90, 101)
+    mel, rel = feature_errors(f, ref)
+    print(f"process {orig_sr} Hz x{channels}: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL

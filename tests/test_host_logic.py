@@ -59,8 +59,11 @@ def test_preprocessor_interface_and_errors():
         cda.AudioPreprocessor(n_fft=1024, **SHIPPED)
     with pytest.raises(ValueError, match="16000"):
         p.extract_features(torch.zeros(1, 8000))
-    with pytest.raises(ValueError):
-        p.resample(torch.zeros(1, 44100), 44100)
+    same = torch.zeros(1, 16000)
+    assert p.resample(same, 16000) is same                   # same rate: untouched, as the reference (:179-180)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            p.resample(torch.zeros(1, 44100), 44100)
     x = torch.arange(10.0).reshape(1, 10)
     assert torch.equal(p.pad_or_trim(x, 4), ofeat.pad_or_trim(x, 4))
     assert torch.equal(p.pad_or_trim(x, 15), ofeat.pad_or_trim(x, 15))

@@ -133,3 +133,21 @@ def test_realtime_windower_counts():
     assert w.buffer.shape[1] == 32000 - 5 * 4000
     w.reset()
     assert w.buffer.shape == (1, 0)
+
+
+def test_resampler_restatement_properties():
+    # T.Resample(44100 -> 16000): gcd 100 -> 441:160, width = ceil(6*441/(160*0.99)) = 17, K = 475
+    k, width, orig, new = F.sinc_resample_kernel(44100, 16000)
+    assert (width, orig, new) == (17, 441, 160) and k.shape == (160, 1, 475)
+    from cough_detector_amd import _tables
+    assert torch.equal(k.reshape(160, 475), _tables.sinc_resample_kernel(44100, 16000)[0])
+    x = torch.randn(2, 30000)
+    assert F.resample(x, 16000) is x
+    assert F.resample(x, 44100).shape == (2, int(np.ceil(160 * 30000 / 441)))
+    dc = F.resample(torch.ones(1, 44100), 44100)[0, 200:-200]
+    assert (dc - 1).abs().max() < 2e-3                  # unity DC gain away from the edges
+    t = torch.arange(44100) / 44100.0
+    r = F.resample(torch.sin(2 * torch.pi * 1000 * t)[None], 44100)[0]
+    t2 = torch.arange(16000) / 16000.0
+    assert (r[100:-100] - torch.sin(2 * torch.pi * 1000 * t2)[100:-100]).abs().max() < 2e-3
+    assert F.process(x[:, :20000], 44100).shape == (1, 90, 101)       # short clip is centre-padded
