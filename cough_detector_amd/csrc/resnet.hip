@@ -1024,7 +1024,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
         const Blk& k = blk[i];
         if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
             using Cfg0 = RbCfg<32, 64, 1, 3, 4>;     // block 0: 1 clip (66 KB LDS: two workgroups per CU), 4 waves = 2 tile groups x 2 channel tiles
-            using Cfg1 = RbCfg<64, 128, 3, 4, 4>;    // block 1: 3 clips, 4 waves = all 4 pixel tiles x 4 channel tiles
+            using Cfg1 = RbCfg<64, 128, 3, 2, 8>;    // block 1: 3 clips, 8 waves = 2 pixel-tile pairs x 4 channel tiles (2 waves per SIMD)
             RbArgs ra{};
             ra.x = reinterpret_cast<const bf16_t*>(k.x); ra.XH = k.xh; ra.XW = k.xw; ra.OH = k.oh; ra.OW = k.ow;
             ra.n_clips = n;
@@ -1041,7 +1041,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                 if (i == 0)
                     hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 1, 3, 4>), grid, dim3(Cfg0::THREADS), lds, st, ra);
                 else
-                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 4, 4>), grid, dim3(Cfg1::THREADS), lds, st, ra);
+                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 2, 8>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
                 if (i == 1) head_done = true;
                 continue;
@@ -1136,7 +1136,7 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 1, 3, 4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 4, 4>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 2, 8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("cough_resnet_create: %s", hipGetErrorString(e));
