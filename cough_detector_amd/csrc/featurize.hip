@@ -480,27 +480,61 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         const float bn = stem.bias[sr];
         const int q = sr >> 2, dy = (sr >> 1) & 1, dx = sr & 1;
         uint16_t* oa = stem.a1 + clip * (long long)ST_PER * 32;
-        for (int tile = wave; tile < ST_TILES; tile += WAVES) {
+        auto frag_base = [&](int tile) -> const uint32_t* {
             int P = tile * 8 + q;
             if (P >= ST_PER) P = ST_PER - 1;
             const int ph = P / ST_P1W, pw = P - ph * ST_P1W;
-            const uint32_t* base =
-                reinterpret_cast<const uint32_t*>(img + (2 * (2 * ph + dy) + sh) * ST_PITCH + 2 * (2 * pw + dx));
-            f32x16 acc2 = {0};
+            return reinterpret_cast<const uint32_t*>(img + (2 * (2 * ph + dy) + sh) * ST_PITCH + 2 * (2 * pw + dx));
+        };
+        auto load_frags = [&](const uint32_t* base, bf16x8 (&a)[4]) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const uint32_t* p = base + st * ST_PITCH;   // +2 image rows per step = ST_PITCH dwords
-                union { uint32_t u[4]; bf16x8 v; } a;
-                a.u[0] = p[0]; a.u[1] = p[1]; a.u[2] = p[2]; a.u[3] = p[3];
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[st], acc2, 0, 0, 0);
+                union { uint32_t u[4]; bf16x8 v; } t;
+                t.u[0] = p[0]; t.u[1] = p[1]; t.u[2] = p[2]; t.u[3] = p[3];
+                a[st] = t.v;
             }
+        };
+        auto epilogue = [&](int tile, const f32x16& acc2, bool guard) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int Po = tile * 8 + 2 * g + sh;
                 float v = fmaxf(fmaxf(acc2[4 * g], acc2[4 * g + 1]), fmaxf(acc2[4 * g + 2], acc2[4 * g + 3])) + bn;
                 v = fmaxf(v, 0.f);
-                if (Po < ST_PER) oa[Po * 32 + sr] = f2bf(v);
+                if (!guard || Po < ST_PER) oa[Po * 32 + sr] = f2bf(v);
             }
+        };
+        // ST_TILES = 69: every wave owns 17 full tiles (wave, wave+4, ..., wave+64), taken two at a time so one
+        // tile's LDS latency and epilogue overlap the other's MFMAs; wave 0 finishes the partial tile 68.
+        static_assert(ST_TILES == 17 * WAVES + 1, "stem tile split");
+        for (int it = 0; it < 16; it += 2) {
+            const int ta = wave + WAVES * it, tbb = ta + WAVES;
+            bf16x8 fa[4], fb[4];
+            load_frags(frag_base(ta), fa);
+            load_frags(frag_base(tbb), fb);
+            f32x16 ca = {0}, cb = {0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st], bw[st], ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st], bw[st], cb, 0, 0, 0);
+            }
+            epilogue(ta, ca, false);
+            epilogue(tbb, cb, false);
+        }
+        {
+            const int ta = wave + WAVES * 16;               // 17th full tile
+            const bool last = wave == 0;                    // wave 0 also takes the partial tile 68
+            bf16x8 fa[4], fb[4];
+            load_frags(frag_base(ta), fa);
+            load_frags(frag_base(last ? ST_TILES - 1 : ta), fb);
+            f32x16 ca = {0}, cb = {0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st], bw[st], ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st], bw[st], cb, 0, 0, 0);
+            }
+            epilogue(ta, ca, false);
+            if (last) epilogue(ST_TILES - 1, cb, true);
         }
     }
 }
