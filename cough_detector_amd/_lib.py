@@ -9,7 +9,8 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcough_amd.so")
+# COUGH_AMD_LIB: alternative build of the same ABI (same-box A/B timing of kernel variants)
+LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.so")
 
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1

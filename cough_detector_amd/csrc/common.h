@@ -29,14 +29,28 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---- wave64 / block reductions -------------------------------------------------------------
+// DPP reductions (no LDS crossbar round trips): quad swaps, half-row / row mirrors give every lane its
+// 16-lane row total; two xor-shuffles then combine the four rows.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror: every lane holds its row's max
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);            // every lane holds its row's sum
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 

@@ -768,11 +768,12 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
         if (a.fcw != nullptr) {
             float* hred = reinterpret_cast<float*>(otile + Cfg::MTMAX * 32 * OPITCH);   // [THREADS/64][2]
             const int c = tid & 127;
-            for (int g0 = 0; g0 < G; g0 += THREADS / 128) {
+            for (int g0 = 0; g0 < G; g0 += THREADS / 128) {   // one pass when THREADS/128 >= G
                 const int g = g0 + (tid >> 7);
                 float l0 = 0.f, l1 = 0.f;
                 if (g < G) {
                     float sum = 0.f;
+#pragma unroll 6
                     for (int i = 0; i < per; ++i) sum += bf2f(otile[(g * per + i) * OPITCH + c]);
                     const float mean = sum / float(per);
                     l0 = wave_sum(mean * a.fcw[c]);

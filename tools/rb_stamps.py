@@ -25,7 +25,7 @@ assert lib.cough_debug_set_rb_stamp_buffer(None) == 0
 # both block kernels wrote the same buffer; block1 ran last with ceil(B/3) workgroups, block0 with B/2 before it
 st = stamps.view(4096, 8).cpu().double()
 n1 = (B + 2) // 3
-for name, rows in (("block1 (G=3, 4 waves)", st[:n1]), ("block0 (G=2, 6 waves) [rows not overwritten by block1]", st[n1:B // 2])):
+for name, rows in (("block1 (G=3, 8 waves)", st[:n1]), ("block0 (G=1, 4 waves) [rows not overwritten by block1]", st[n1:B])):
     d = rows[:, 1:7] - rows[:, 0:6]; total = rows[:, 6] - rows[:, 0]
     print(name, "median total", float(total.median()))
     for i, n in enumerate(NAMES):
