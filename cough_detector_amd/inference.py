@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .model import create_model
+from .pipeline import CoughPipeline
 from .preprocessing import RealtimePreprocessor
 
 
@@ -66,6 +67,7 @@ class CoughDetectorInference:
             use_delta_delta=cfg.get("use_delta_delta", True),
             use_spectral_contrast=cfg.get("use_spectral_contrast", True),
             n_contrast_bands=cfg.get("n_contrast_bands", 6), device="cuda")
+        self._pipeline = CoughPipeline(self.preprocessor, self.model)   # windows -> probabilities in one C-ABI call
         self.prediction_history = deque(maxlen=smoothing_window)
         self.last_detection_time = 0
         self.on_cough_detected: Optional[Callable[[datetime, float], None]] = None
@@ -115,8 +117,8 @@ class CoughDetectorInference:
         windows = self.preprocessor.take_windows(audio_chunk)
         if windows is None:
             return None
-        feats = self.preprocessor.featurize_batch(windows, normalize=True)       # stays on the GPU
-        probs = self.predict_batch(feats).tolist()
+        _, p2 = self._pipeline.predict(windows, normalize=True)                  # normalise + featurise + classify
+        probs = p2[:, 1].to("cpu").tolist()                                      # the one host sync of the chunk
         for confidence in probs:
             self.window_probs.append(confidence)
             self.prediction_history.append(confidence)
