@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_CLIP = 64000 + 36360          # featurise: waveform read + (90,101) f32 written
+BYTES_PER_CLIP_STFT = 64000 + 103828    # STFT stage alone: waveform read + (257,101) f32 power written
 BYTES_PER_CLIP_FUSED = 64000 + 35200    # featurise + bf16 stem fused: waveform read + (22,25,32) bf16 written
 FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
 FLOP_PER_CLIP_NO_STEM = 35668480        # minus the stem's 32*45*51*49 MAC (it runs inside the featurise kernel)
@@ -48,6 +49,30 @@ def measured_traffic(batch: int, fused: bool = False):
     except (OSError, KeyError, ValueError):
         pass
     return None, None
+
+
+def stft_stage(pre, wav, launches: int = 20) -> dict:
+    """The STFT stage on its own (cough_spectrogram = the reference's T.Spectrogram, preprocessing.py:131-136):
+    waveform in, 257x101 power spectrogram out, timed with HIP events on the launch stream.  Reported beside the
+    headline because BASELINE.json quotes an HBM fraction "for the STFT stage"; the fused featuriser above never
+    writes this tensor."""
+    import torch
+    b = wav.shape[0]
+    spec = torch.empty((b, 257, 101), dtype=torch.float32, device=wav.device)
+    for _ in range(3):
+        pre.spectrogram_batch(wav, out=spec)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        pre.spectrogram_batch(wav, out=spec)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    achieved = b * BYTES_PER_CLIP_STFT / (ms * 1e-3) / 1e9
+    return {"kernel": "stft_kernel (waveform -> 257x101 power spectrogram)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),
+            "algorithmic_bytes_per_launch": b * BYTES_PER_CLIP_STFT}
 
 
 def cpu_baseline(budget_s: float) -> dict:
@@ -219,6 +244,8 @@ def main():
                                            "bound": "mfma",
                                            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                            "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4)}
+        if world == 1:
+            line["roofline_stft"] = stft_stage(pre, wav)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.s
 
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1
+SPEC_MAGNITUDE, SPEC_FULL_WINDOW = 1, 2
 DTYPE_FP32, DTYPE_BF16, _DTYPE_DIRECT = 0, 1, 2
 DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT}
 
@@ -21,7 +22,7 @@ DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT}
 SYMBOLS = (
     "cough_amd_abi_version", "cough_amd_arch", "cough_amd_last_error",
     "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
-    "cough_featurizer_num_frames", "cough_featurize",
+    "cough_featurizer_num_frames", "cough_featurize", "cough_spectrogram",
     "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
@@ -78,6 +79,7 @@ def load() -> C.CDLL:
         lib.cough_featurizer_num_features.argtypes = [vp]
         lib.cough_featurizer_num_frames.argtypes = [vp]
         lib.cough_featurize.argtypes = [vp, vp, ll, vp, i, i, vp]
+        lib.cough_spectrogram.argtypes = [vp, vp, ll, vp, i, i, vp]
         lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
         lib.cough_resnet_destroy.argtypes = [vp]
         lib.cough_resnet_destroy.restype = None

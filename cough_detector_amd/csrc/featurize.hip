@@ -27,12 +27,14 @@
 // Only bins 4..127 feed the shipped 100 Hz-4 kHz filterbank, so the upper half
 // of the spectrum is never formed.
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <vector>
 
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "fft256.h"
 #include "internal.h"
 
 namespace cough {
@@ -67,55 +69,6 @@ constexpr size_t LDS_TOTAL = LDS_XCH + LDS_MEL + LDS_RED + LDS_TW;
 static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
 static_assert(LDS_XCH >= size_t(2) * NMF * 4, "MFCC / delta buffers alias the transpose scratch");
 
-constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, RH = 0.70710678118654752f;
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// a * W16^M, W16 = exp(-2*pi*i/16)
-template <int M>
-__device__ __forceinline__ float2 mul_w16(float2 a) {
-    if constexpr (M == 0) return a;
-    else if constexpr (M == 4) return make_float2(a.y, -a.x);
-    else if constexpr (M == 2) return make_float2(RH * (a.x + a.y), RH * (a.y - a.x));
-    else if constexpr (M == 6) return make_float2(RH * (a.y - a.x), -RH * (a.x + a.y));
-    else {
-        constexpr float c = (M == 1) ? C1 : (M == 3) ? S1 : -C1;   // M == 9: (-C1, -S1)
-        constexpr float s = (M == 1) ? S1 : (M == 3) ? C1 : -S1;
-        return make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
-    }
-}
-
-__device__ __forceinline__ void radix4(float2& a0, float2& a1, float2& a2, float2& a3) {
-    const float2 s0 = make_float2(a0.x + a2.x, a0.y + a2.y), s1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-    const float2 s2 = make_float2(a1.x + a3.x, a1.y + a3.y), s3 = make_float2(a1.x - a3.x, a1.y - a3.y);
-    a0 = make_float2(s0.x + s2.x, s0.y + s2.y);
-    a2 = make_float2(s0.x - s2.x, s0.y - s2.y);
-    a1 = make_float2(s1.x + s3.y, s1.y - s3.x);
-    a3 = make_float2(s1.x - s3.y, s1.y + s3.x);
-}
-
-// In-register forward 16-point DFT, natural order in and out (radix-4 x radix-4).
-__device__ __forceinline__ void dft16(float2 (&x)[16]) {
-    float2 t[16];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) {
-        float2 a0 = x[n2], a1 = x[4 + n2], a2 = x[8 + n2], a3 = x[12 + n2];
-        radix4(a0, a1, a2, a3);
-        t[4 * n2 + 0] = a0; t[4 * n2 + 1] = a1; t[4 * n2 + 2] = a2; t[4 * n2 + 3] = a3;
-    }
-    t[5] = mul_w16<1>(t[5]);   t[6] = mul_w16<2>(t[6]);   t[7] = mul_w16<3>(t[7]);
-    t[9] = mul_w16<2>(t[9]);   t[10] = mul_w16<4>(t[10]); t[11] = mul_w16<6>(t[11]);
-    t[13] = mul_w16<3>(t[13]); t[14] = mul_w16<6>(t[14]); t[15] = mul_w16<9>(t[15]);
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-        float2 b0 = t[k1], b1 = t[4 + k1], b2 = t[8 + k1], b3 = t[12 + k1];
-        radix4(b0, b1, b2, b3);
-        x[k1] = b0; x[k1 + 4] = b1; x[k1 + 8] = b2; x[k1 + 12] = b3;
-    }
-}
-
 __device__ __forceinline__ float block_max(float v, float* red, int tid) {
     v = wave_max(v);
     __syncthreads();
@@ -149,14 +102,6 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #else
 #define K1_STAMP(slot) do { } while (0)
 #endif
-
-// W32^k2 = exp(-2*pi*i*k2/32), k2 = 0..7 (compile-time constants of the real-input split)
-__device__ constexpr float W32C[8] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
-                                      0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f,
-                                      0.19509032201612825f};
-__device__ constexpr float W32S[8] = {0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
-                                      -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f,
-                                      -0.98078528040323043f};
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -546,6 +491,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 struct cough_featurizer {
     cough_feat_config cfg;
     cough::FeatTables* d_tables;
+    float* d_win_full;   // periodic Hann(n_fft), for cough_spectrogram(COUGH_SPEC_FULL_WINDOW)
     int nfeat;
 };
 
@@ -594,11 +540,17 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     f->cfg = *cfg;
     f->nfeat = NMEL + 2 * NMFCC + (cfg->use_delta_delta ? NMFCC : 0);
     f->d_tables = nullptr;
+    f->d_win_full = nullptr;
+    std::vector<float> hann(NFFT);   // torch.hann_window(n_fft, periodic=True)
+    for (int n = 0; n < NFFT; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(NFFT)));
     hipError_t e = hipMalloc(&f->d_tables, sizeof(FeatTables));
     if (e == hipSuccess) e = hipMemcpy(f->d_tables, &t, sizeof(FeatTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&f->d_win_full, NFFT * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(f->d_win_full, hann.data(), NFFT * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("cough_featurizer_create: %s", hipGetErrorString(e));
         if (f->d_tables) (void)hipFree(f->d_tables);
+        if (f->d_win_full) (void)hipFree(f->d_win_full);
         delete f;
         return COUGH_EHIP;
     }
@@ -615,6 +567,7 @@ extern "C" int cough_debug_set_stamp_buffer(void* d_buf) {
 extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
     if (!f) return;
     if (f->d_tables) (void)hipFree(f->d_tables);
+    if (f->d_win_full) (void)hipFree(f->d_win_full);
     delete f;
 }
 
@@ -622,6 +575,12 @@ extern "C" int cough_featurizer_num_features(const cough_featurizer* f) { return
 extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return f ? cough::NFRAMES : -1; }
 
 namespace cough {
+StftView featurizer_stft_view(const cough_featurizer* f) {
+    const char* base = reinterpret_cast<const char*>(f->d_tables);
+    return StftView{reinterpret_cast<const float*>(base + offsetof(FeatTables, win)), f->d_win_full,
+                    reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw256)),
+                    reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw512))};
+}
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 bool featurizer_stem_fusable(const cough_featurizer* f) {
     return f->nfeat == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;

@@ -22,4 +22,15 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
 int featurizer_num_features(const cough_featurizer* f);
 bool featurizer_stem_fusable(const cough_featurizer* f);   // shipped 90-row layout, no pre-emphasis, no PCEN
 
+// Device tables of a featuriser that the stand-alone STFT (spectrogram.hip) shares.
+struct StftView {
+    const float* win;        // [512] the caller's window centred in the frame (Hann(400): 56|400|56)
+    const float* win_full;   // [512] periodic Hann(512) (T.SpectralCentroid's default window)
+    const float2* tw256;     // [16][16] W256^(j*k1)
+    const float2* tw512;     // [128] W512^k
+};
+StftView featurizer_stft_view(const cough_featurizer* f);
+int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+                hipStream_t stream);
+
 }  // namespace cough

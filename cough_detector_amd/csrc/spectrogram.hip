@@ -1,0 +1,256 @@
+// Stand-alone STFT for gfx950: waveform -> |X|^2 (or |X|) spectrogram, (n, 257, 101) float32.
+//
+// Replaces the T.Spectrogram(n_fft=512, win_length=400, hop_length=160, power=2) transform of
+// /root/reference/src/preprocessing.py:131-136 (torch.stft(center=True, pad_mode="reflect", onesided=True),
+// periodic Hann(400) zero-padded to 512) and, with COUGH_SPEC_FULL_WINDOW | COUGH_SPEC_MAGNITUDE, the magnitude
+// spectrogram T.SpectralCentroid computes internally with its default Hann(n_fft) window (:137-141).
+//
+// The fused featuriser (featurize.hip) never materialises the spectrogram; this kernel is the same FFT with all
+// 257 bins formed and stored.  Algorithmic bytes per clip: 64 000 read + 257*101*4 = 103 828 written.
+//
+// Work item = (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames); a persistent grid of 4-wave
+// workgroups (three resident per CU) walks the items.  A wave transforms 4 frames at a time (16 lanes each): lane
+// j of a frame ends up with Z[j+16*k2]; with its partner's Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and
+// X[256-k] -- conj(E - W^k O) -- so every bin 0..256 comes out of the same 8 butterflies.  The (bin, time) output
+// is time-minor, so the chunk's powers are staged in LDS and flushed as ~100-byte row fragments; the stores drain
+// while the workgroup transforms its next item (a workgroup that ended after each flush would hold its LDS until
+// the stores are acknowledged).  The four chunks of a clip are taken in the same sweep by workgroups 8 ids apart:
+// same XCD (ids are dealt round-robin over the 8 XCDs), same time, so the fragments of one 404-byte row meet in
+// that XCD's L2 and leave as whole lines (WRITE_SIZE = 1.07x the algorithmic bytes).
+#include "common.h"
+#include "fft256.h"
+#include "internal.h"
+
+namespace cough {
+namespace {
+
+constexpr int NS = 16000, NFFT = 512, HOP = 160, NFRAMES = 101, NFREQ = 257;
+constexpr int PADL = NFFT / 2;
+constexpr int THREADS = 256, WAVES = 4, FPW = 4;
+constexpr int NGROUP = (NFRAMES + FPW - 1) / FPW;           // 26 groups of 4 frames
+constexpr int NCHUNK = 4;
+__device__ constexpr int CHUNK_G0[NCHUNK + 1] = {0, 7, 14, 20, 26};   // first group of each chunk: every wave has 1-2 groups
+constexpr int CHUNK_MAX = 7 * FPW;                          // frames staged per item (<= 28)
+constexpr int XROW = 17, XFRAME = 16 * XROW;
+constexpr int FIRST_PLAIN = 2, LAST_PLAIN = 98;             // frames whose 512 samples lie inside the clip
+constexpr int PITCH = CHUNK_MAX + 1;                        // 29, odd: the 16 lanes of a frame hit 16 banks
+constexpr int FLUSH_COLS = 32;                              // flush thread layout: 32 columns x 8 rows per sweep
+constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 4;   // 17408
+constexpr size_t LDS_PW = size_t(NFREQ) * PITCH * 4;           // 29812
+constexpr size_t LDS_TW = size_t(16) * XROW * 8;               // 2176
+constexpr size_t LDS_TOTAL = LDS_XCH + LDS_TW + LDS_PW;
+static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
+static_assert(LDS_XCH % 16 == 0 && LDS_TW % 16 == 0, "float2 table and staging rows start 16-byte aligned");
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, and a fence is
+// a vmcnt(0) -- it would wait for the samples fetched ahead and for the previous flush's stores.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// FULLWIN: all 512 window taps are live (Hann(512)); otherwise taps [0,56) and [456,512) are zero (Hann(400)
+// centred in the frame) and the first / last 32-sample slabs are never loaded.
+template <bool FULLWIN, bool MAG>
+__global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restrict__ wav, long long wav_stride,
+                                                          float* __restrict__ out, const float* __restrict__ win,
+                                                          const float2* __restrict__ tw256,
+                                                          const float2* __restrict__ tw512, int n_clips,
+                                                          int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);
+    float2* twl = reinterpret_cast<float2*>(smem + LDS_XCH);              // [16][XROW], 8-byte aligned (ds_read2_b64)
+    float* pw = reinterpret_cast<float*>(smem + LDS_XCH + LDS_TW);        // [257][PITCH]
+    constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // item id i = slab * 8 + r: clip = (slab / NCHUNK) * 8 + r, chunk = slab % NCHUNK
+    auto decode = [&](int item, long long& clip, int& chunk) {
+        const int slab = item >> 3;
+        clip = (long long)(slab / NCHUNK) * 8 + (item & 7);
+        chunk = slab % NCHUNK;
+    };
+    long long clip;
+    int chunk;
+    decode(blockIdx.x, clip, chunk);
+    const int j = lane & 15, fsub = lane >> 4;
+    const float2* tw_row = twl + j * XROW;
+    const float2 tw_j = tw512[j];
+    float* myx = xs + (wave * FPW + fsub) * XFRAME;
+
+    // 14 (16) eight-byte loads of the 4 frames of group g of the clip at xc
+    auto load_group = [&](const float* xc, int g, float2 (&raw)[16]) {
+        const int t_raw = FPW * g + fsub;
+        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames of group 25 redo the last frame
+        const int s0 = HOP * t - PADL + 2 * j;
+        if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
+#pragma unroll
+            for (int n1 = N0; n1 < N1; ++n1) raw[n1] = *reinterpret_cast<const float2*>(xc + s0 + 32 * n1);
+        } else {   // reflect padding of torch.stft(center=True)
+#pragma unroll
+            for (int n1 = N0; n1 < N1; ++n1) {
+                int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                raw[n1] = make_float2(xc[i0], xc[i1]);
+            }
+        }
+    };
+    float2 raw[16];
+    if (clip < n_clips) load_group(wav + clip * wav_stride, CHUNK_G0[chunk] + wave, raw);
+    // window taps and the W256 table arrive while the first samples are on their way from HBM
+    float w_re[16], w_im[16];
+#pragma unroll
+    for (int n1 = N0; n1 < N1; ++n1) {
+        w_re[n1] = win[32 * n1 + 2 * j];
+        w_im[n1] = win[32 * n1 + 2 * j + 1];
+    }
+    twl[(tid >> 4) * XROW + (tid & 15)] = tw256[tid];
+    __syncthreads();
+
+    // clips past n_clips (last slab group only) are the last items of the workgroups that own them
+    for (int item = blockIdx.x; item < n_items && clip < n_clips; item += gridDim.x) {
+        long long nclip = n_clips;
+        int nchunk = 0;
+        if (item + (int)gridDim.x < n_items) decode(item + gridDim.x, nclip, nchunk);
+        const bool more = nclip < n_clips;                  // workgroup-uniform
+        const float* x = wav + clip * wav_stride;
+        const int gs = CHUNK_G0[chunk], ge = CHUNK_G0[chunk + 1];
+#pragma unroll 1
+        for (int g = gs + wave; g < ge; g += WAVES) {       // 1 or 2 groups per wave
+            float2 a[16];
+            if constexpr (!FULLWIN) {
+                a[0] = make_float2(0.f, 0.f);
+                a[15] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int n1 = N0; n1 < N1; ++n1) a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
+            // the raw registers are free: the wave's next group (of this item, else the first of the next item)
+            // starts moving now and lands during this FFT
+            {
+                const bool same = g + WAVES < ge;
+                const float* xn = same ? x : wav + nclip * wav_stride;
+                const int gn = same ? g + WAVES : CHUNK_G0[nchunk] + wave;
+                if (same || more) load_group(xn, gn, raw);
+            }
+            dft16(a);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
+            float2 z[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].x;
+            wave_lds_fence();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].x = myx[j * XROW + n2];
+            wave_lds_fence();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].y;
+            wave_lds_fence();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * XROW + n2];
+            wave_lds_fence();
+            dft16(z);   // z[k2] = Z[j + 16*k2]
+
+            const int src = (lane & 48) | ((16 - j) & 15);
+            float2 rv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                rv[r].x = __shfl(z[8 + r].x, src, 64);
+                rv[r].y = __shfl(z[8 + r].y, src, 64);
+            }
+            const bool live = FPW * g + fsub < NFRAMES;   // idle sub-frames of the last group store nothing
+            float* col = pw + (g - gs) * FPW + fsub;
+            auto put = [&](int bin, float pwr4) {   // pwr4 = |2X|^2
+                col[bin * PITCH] = MAG ? 0.5f * sqrtf(pwr4) : 0.25f * pwr4;
+            };
+            if (live) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 zk = z[k2];
+                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+                    // 2E = Zk + conj Zp, 2O = -i (Zk - conj Zp); 2X[k] = 2E + W^k 2O, 2X[256-k] = conj(2E - W^k 2O)
+                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+                    const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+                    const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+                    const int k = j + 16 * k2;
+                    put(k, ar * ar + ai * ai);
+                    put(NFFT / 2 - k, br * br + bi * bi);
+                }
+                if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
+            }
+            wave_lds_fence();
+        }
+        lds_barrier();
+        {
+            // A fixed number of stores per thread (32 + the odd row), fully unrolled: vmcnt counts loads and stores in
+            // issue order, so the wait for the samples fetched ahead (issued before these stores) can only leave the
+            // stores in flight if their count is a compile-time constant.
+            const int t0 = gs * FPW;
+            const int nv = (ge * FPW < NFRAMES ? ge * FPW : NFRAMES) - t0;
+            float* o = out + clip * (long long)NFREQ * NFRAMES + t0;
+            constexpr int ROWS_PER_IT = THREADS / FLUSH_COLS;   // 8
+            static_assert(NFREQ == 32 * ROWS_PER_IT + 1, "flush shape");
+            const int c = tid & (FLUSH_COLS - 1), r0 = tid / FLUSH_COLS;
+            if (c < nv) {
+                const float* src = pw + r0 * PITCH + c;
+                float* dst = o + r0 * NFRAMES + c;
+#pragma unroll
+                for (int it = 0; it < 32; ++it) dst[it * ROWS_PER_IT * NFRAMES] = src[it * ROWS_PER_IT * PITCH];
+                if (r0 == 0) dst[256 * NFRAMES] = src[256 * PITCH];
+            }
+        }
+        if (more) lds_barrier();   // the staging buffer is free for the next item
+        clip = nclip;
+        chunk = nchunk;
+    }
+}
+
+}  // namespace
+
+int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+                hipStream_t stream) {
+    static int n_cus = 0;   // same device for the life of the process (one process per GPU)
+    if (n_cus == 0) {
+        int dev = 0, cus = 0;
+        COUGH_HIP_CHECK(hipGetDevice(&dev));
+        COUGH_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cus = cus > 0 ? cus : 256;
+    }
+    const int n_items = ((n_clips + 7) / 8) * 8 * NCHUNK;
+    // resident slots, rounded down to a multiple of 8 * NCHUNK so that ids 8 apart stay on one clip's chunks
+    int slots = (n_cus * 3) / (8 * NCHUNK) * (8 * NCHUNK);
+    if (slots < 8 * NCHUNK) slots = 8 * NCHUNK;
+    const dim3 grid(n_items < slots ? n_items : slots), block(THREADS);
+    const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
+    const float* win = full ? v.win_full : v.win;
+#define COUGH_STFT_LAUNCH(F, M)                                                                              \
+    hipLaunchKernelGGL((stft_kernel<F, M>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_spec, win, \
+                       v.tw256, v.tw512, n_clips, n_items)
+    if (full && mag) COUGH_STFT_LAUNCH(true, true);
+    else if (full) COUGH_STFT_LAUNCH(true, false);
+    else if (mag) COUGH_STFT_LAUNCH(false, true);
+    else COUGH_STFT_LAUNCH(false, false);
+#undef COUGH_STFT_LAUNCH
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+}  // namespace cough
+
+extern "C" int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_spec,
+                                 int n_clips, int flags, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(f && d_wav && d_spec, COUGH_EINVAL, "cough_spectrogram: NULL argument");
+    COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_spectrogram: n_clips < 0");
+    COUGH_REQUIRE((flags & ~(COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW)) == 0, COUGH_EINVAL,
+                  "cough_spectrogram: unknown flag bits 0x%x", flags);
+    COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
+                  COUGH_EINVAL, "cough_spectrogram: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
+    if (n_clips == 0) return COUGH_OK;
+    return launch_stft(featurizer_stft_view(f), d_wav, wav_stride, d_spec, n_clips, flags,
+                       static_cast<hipStream_t>(stream));
+}

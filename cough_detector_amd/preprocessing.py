@@ -214,6 +214,34 @@ class AudioPreprocessor:
                    "cough_featurize")
         return out
 
+    def spectrogram_batch(self, waveforms: torch.Tensor, power: float = 2.0, full_window: bool = False,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The STFT stage on its own: (B, segment_samples) -> (B, n_fft//2+1, T) float32 on the GPU.
+
+        ``power=2.0`` with the featuriser's window is the reference's ``self.spectrogram`` (T.Spectrogram,
+        preprocessing.py:131-136); ``power=1.0, full_window=True`` is the magnitude spectrogram
+        ``T.SpectralCentroid`` (:137-141) forms with its default Hann(n_fft) window."""
+        if waveforms.dim() != 2 or waveforms.shape[1] != self.segment_samples:
+            raise ValueError(f"spectrogram_batch: expected (B, {self.segment_samples}), got {tuple(waveforms.shape)}")
+        if power not in (1.0, 2.0):
+            raise ValueError("spectrogram_batch: power must be 1.0 or 2.0")
+        dev = _cuda_device()
+        w = waveforms.to(device=dev, dtype=torch.float32)
+        if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
+            w = w.contiguous()
+        b, shape = w.shape[0], (w.shape[0], self.n_fft // 2 + 1, self.get_expected_time_frames())
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("spectrogram_batch: `out` must be a contiguous float32 (B, 257, T) tensor on the GPU")
+        if b == 0:
+            return out
+        flags = (_lib.SPEC_MAGNITUDE if power == 1.0 else 0) | (_lib.SPEC_FULL_WINDOW if full_window else 0)
+        _lib.check(_lib.load().cough_spectrogram(self._native(), w.data_ptr(), w.stride(0) if b > 1 else
+                                                 self.segment_samples, out.data_ptr(), b, flags,
+                                                 torch.cuda.current_stream(dev).cuda_stream), "cough_spectrogram")
+        return out
+
     def extract_features(self, waveform: torch.Tensor) -> torch.Tensor:
         """(1, N) -> (1, F, T) like the reference; also (B, N) / (B, 1, N) -> (B, F, T)."""
         if waveform.dim() == 3:

@@ -79,6 +79,17 @@ int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_ti
 int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                     float* d_feat, int n_clips, int flags, void* stream);
 
+/* Stand-alone STFT: T.Spectrogram(n_fft=512, win_length=400, hop_length=160, power=2.0) of
+ * /root/reference/src/preprocessing.py:131-136 (the "STFT stage" on its own; cough_featurize never
+ * materialises it).  d_spec: [n_clips][n_fft/2+1 = 257][num_frames = 101] float32.
+ * flags: COUGH_SPEC_MAGNITUDE -> power=1.0; COUGH_SPEC_FULL_WINDOW -> periodic Hann(n_fft) instead of the
+ * featuriser's window (both together = the spectrogram T.SpectralCentroid(sample_rate, n_fft, hop_length)
+ * forms internally, :137-141). */
+#define COUGH_SPEC_MAGNITUDE 1
+#define COUGH_SPEC_FULL_WINDOW 2
+int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride,
+                      float* d_spec, int n_clips, int flags, void* stream);
+
 /* ------------------------------------------------------------------ classifier (K2-K5)
  * Replaces CoughDetectorResidual.forward / predict and ResidualBlock.forward
  * (/root/reference/src/model.py:210-293) in eval mode.  Pointers are HOST float32

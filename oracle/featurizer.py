@@ -81,15 +81,17 @@ def create_dct(n_mfcc: int = N_MFCC, n_mels: int = N_MELS) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- transforms
-def stft_power(waveform: torch.Tensor, n_fft: int = N_FFT, hop: int = HOP, win: int = WIN) -> torch.Tensor:
-    """(..., N) -> (..., n_fft//2+1, 1+N//hop) power spectrogram (F1)."""
+def stft_power(waveform: torch.Tensor, n_fft: int = N_FFT, hop: int = HOP, win: int = WIN,
+               power: float = 2.0) -> torch.Tensor:
+    """(..., N) -> (..., n_fft//2+1, 1+N//hop) spectrogram (F1): torchaudio.functional.spectrogram with
+    pad=0, normalized=False, center=True, reflect padding; ``power=2`` is |X|^2, ``power=1`` is |X|."""
     shape = waveform.shape
     w = waveform.reshape(-1, shape[-1])
     spec = torch.stft(w, n_fft=n_fft, hop_length=hop, win_length=win, window=hann_window(win),
                       center=True, pad_mode="reflect", normalized=False, onesided=True,
                       return_complex=True)
     spec = spec.reshape(shape[:-1] + spec.shape[-2:])
-    return spec.abs().pow(2.0)
+    return spec.abs() if power == 1.0 else spec.abs().pow(power)
 
 
 def mel_spectrogram(waveform: torch.Tensor, fb: Optional[torch.Tensor] = None) -> torch.Tensor:

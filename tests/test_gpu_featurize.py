@@ -177,3 +177,51 @@ def test_process_front_end_resample_mono_normalize_pad(orig_sr, channels, second
     mel, rel = feature_errors(f, ref)
     print(f"process {orig_sr} Hz x{channels}: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
     assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def _spec_err(got, ref, floor_rel=1e-6):
+    """max over elements of |got - ref| / (|ref| + floor_rel * max|ref| of the clip): relative, above the fp32
+    FFT's own noise floor (spectra span > 12 decades inside one clip; an fp32 FFT -- torch's included -- carries
+    ~1e-7 * max|X| of absolute noise in every bin, i.e. 1e-6 * max at tolerance 1e-4 needs floor_rel = 1e-2 for
+    magnitudes; for powers the same amplitude noise sits far below 1e-6 * max power)."""
+    floor = ref.amax(dim=(-1, -2), keepdim=True) * floor_rel + 1e-30
+    return float(((got - ref).abs() / (ref.abs() + floor)).max())
+
+
+@pytest.mark.parametrize("power,full_window", [(2.0, False), (1.0, False), (2.0, True), (1.0, True)])
+def test_stft_stage_against_oracle(pre, power, full_window):
+    """cough_spectrogram = T.Spectrogram(512, 400, 160, power) / SpectralCentroid's internal Hann(512) STFT."""
+    names = sorted(edge_clips().keys())
+    w = torch.cat([synth_batch(300, 24), torch.stack([torch.from_numpy(edge_clips()[n]).float() for n in names])])
+    got = pre.spectrogram_batch(w.cuda(), power=power, full_window=full_window).cpu()
+    assert got.shape == (w.shape[0], 257, 101)
+    ref = ofeat.stft_power(w, win=512 if full_window else 400, power=power)
+    err = _spec_err(got, ref, 1e-6 if power == 2.0 else 1e-2)
+    print(f"stft power={power} full_window={full_window}: rel err {err:.2e}")
+    assert err < FEAT_TOL
+    if power == 2.0 and not full_window:      # and against the float64 DFT, all 257 bins
+        x = w[3].numpy()
+        e64 = _spec_err(got[3].double(), torch.from_numpy(dft64.stft_power(x)))
+        assert e64 < FEAT_TOL
+    zero_row = names.index("zeros") + 24 if "zeros" in names else None
+    if zero_row is not None:
+        assert float(got[zero_row].abs().max()) == 0.0
+
+
+def test_stft_stage_full_batch_parseval(pre):
+    """Size-independent check at B = 4096: Parseval per frame.  For a real frame y (windowed, zero outside the
+    400 live taps) sum_k c_k |Y_k|^2 = 512 * sum_n y_n^2 with c_0 = c_256 = 1, else 2."""
+    B = 4096
+    w = synth_batch(0, 64).repeat(B // 64, 1).cuda()
+    p = pre.spectrogram_batch(w)                                         # (B, 257, 101)
+    c = torch.full((257, 1), 2.0, device="cuda")
+    c[0] = c[256] = 1.0
+    lhs = (p * c).sum(dim=1)                                             # (B, 101)
+    win = torch.zeros(512, device="cuda")
+    win[56:456] = ofeat.hann_window(400).cuda()
+    padded = torch.nn.functional.pad(w[:, None], (256, 256), mode="reflect")[:, 0]
+    frames = padded.unfold(-1, 512, 160) * win                           # (B, 101, 512)
+    rhs = 512.0 * (frames.double() ** 2).sum(-1)
+    rel = ((lhs.double() - rhs).abs() / (rhs + 1e-12 * rhs.max())).max()
+    assert float(rel) < 1e-4
+    assert torch.equal(p[:64], p[-64:])                                  # deterministic across workgroups
