@@ -22,7 +22,8 @@ DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT}
 SYMBOLS = (
     "cough_amd_abi_version", "cough_amd_arch", "cough_amd_last_error",
     "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
-    "cough_featurizer_num_frames", "cough_featurize", "cough_spectrogram",
+    "cough_featurizer_num_frames", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
+    "cough_spectrogram",
     "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
@@ -30,11 +31,15 @@ SYMBOLS = (
 )
 
 
+MAX_CONTRAST_BANDS = 16
+
+
 class FeatConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("n_fft", C.c_int), ("hop_length", C.c_int), ("win_length", C.c_int),
                 ("n_mels", C.c_int), ("n_mfcc", C.c_int), ("segment_samples", C.c_int),
                 ("use_pre_emphasis", C.c_int), ("pre_emphasis_coef", C.c_float), ("use_delta_delta", C.c_int),
-                ("use_pcen", C.c_int)]
+                ("use_pcen", C.c_int), ("use_mfcc", C.c_int), ("use_spectral_contrast", C.c_int),
+                ("n_contrast_bands", C.c_int), ("contrast_edges", C.c_int * (MAX_CONTRAST_BANDS + 2))]
 
 
 _FP = C.POINTER(C.c_float)
@@ -80,6 +85,9 @@ def load() -> C.CDLL:
         lib.cough_featurizer_num_frames.argtypes = [vp]
         lib.cough_featurize.argtypes = [vp, vp, ll, vp, i, i, vp]
         lib.cough_spectrogram.argtypes = [vp, vp, ll, vp, i, i, vp]
+        lib.cough_featurizer_workspace_bytes.argtypes = [vp, i]
+        lib.cough_featurizer_workspace_bytes.restype = C.c_size_t
+        lib.cough_featurize_ws.argtypes = [vp, vp, ll, vp, i, i, vp, C.c_size_t, vp]
         lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
         lib.cough_resnet_destroy.argtypes = [vp]
         lib.cough_resnet_destroy.restype = None
@@ -93,7 +101,7 @@ def load() -> C.CDLL:
         lib.cough_resample.argtypes = [vp, ll, i, i, vp, i, i, i, vp, ll, i, vp]
         lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
         lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]
-        if lib.cough_amd_abi_version() != 1:
+        if lib.cough_amd_abi_version() != 2:
             raise RuntimeError("libcough_amd.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

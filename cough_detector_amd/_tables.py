@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 
@@ -58,3 +59,11 @@ def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: in
     kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
     kernels *= window * scale
     return kernels.to(torch.float32).reshape(new, 2 * width + orig).contiguous(), width, orig, new
+
+
+def contrast_band_edges(n_bands: int, n_freq: int) -> list:
+    """Band edges of extract_spectral_contrast, computed with the reference's own expression
+    (src/preprocessing.py:267-268): ``torch.logspace(0, np.log10(n_freq), n_bands + 2).int()`` clamped to
+    [0, n_freq].  n_bands + 2 integers; the loop uses the first n_bands + 1."""
+    edges = torch.logspace(0, float(np.log10(n_freq)), n_bands + 2).int()
+    return torch.clamp(edges, 0, n_freq).tolist()

@@ -120,7 +120,8 @@ static_assert(size_t(ST_ROWS) * ST_PITCH * 2 <= LDS_MEL, "the bf16 feature image
 template <bool PRE_EMPH, bool STEM>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
-    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta, int pcen, StemFuse stem) {
+    const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
+    1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);
     float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     }
     __syncthreads();
     K1_STAMP(4);   // mel rows written
+    if (delta_delta == 2) return;   // use_mfcc = False: mel rows only (workgroup-uniform)
     // DCT: thread = (frame t, coefficient half); coefficients are wave-uniform -> scalar loads
     float* mf = xs;              // [13][101] z-scored MFCC
     float* dl = mf + NMF;        // delta (needed in LDS only for delta-delta)
@@ -396,14 +398,14 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             o_mfcc[item] = row[t];
             o_delta[item] = d;
         }
-        if (delta_delta) dl[item] = d;
+        if (delta_delta == 1) dl[item] = d;
         if constexpr (STEM) {
             img[(NMEL + c + 3) * ST_PITCH + t + 3] = f2bf(row[t]);
             img[(NMEL + NMFCC + c + 3) * ST_PITCH + t + 3] = f2bf(d);
         }
     }
     K1_STAMP(6);
-    if (delta_delta) {
+    if (delta_delta == 1) {
         __syncthreads();
         float* o_dd = o_delta + NMF;
         for (int item = tid; item < NMF; item += THREADS) {
@@ -492,7 +494,9 @@ struct cough_featurizer {
     cough_feat_config cfg;
     cough::FeatTables* d_tables;
     float* d_win_full;   // periodic Hann(n_fft), for cough_spectrogram(COUGH_SPEC_FULL_WINDOW)
-    int nfeat;
+    int nfeat;           // rows of the feature image
+    int nbase;           // rows the featurise kernel writes (mel [+ MFCC, delta, delta-delta])
+    cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
 };
 
 extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
@@ -505,6 +509,16 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                   COUGH_EUNSUPPORTED,
                   "featuriser geometry not implemented on the HIP path: need sample_rate=16000 n_fft=512 "
                   "hop_length=160 win_length=400 n_mels=64 n_mfcc=13 segment=16000 samples");
+    if (cfg->use_spectral_contrast) {
+        COUGH_REQUIRE(cfg->n_contrast_bands >= 1 && cfg->n_contrast_bands <= COUGH_MAX_CONTRAST_BANDS, COUGH_EUNSUPPORTED,
+                      "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
+        for (int i = 0; i <= cfg->n_contrast_bands; ++i) {
+            const int lo = cfg->contrast_edges[i], hi = cfg->contrast_edges[i + 1];
+            COUGH_REQUIRE(lo >= 0 && lo < NFFT / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= 128), COUGH_EUNSUPPORTED,
+                          "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= 128 bins inside "
+                          "the spectrum", i, lo, hi);
+        }
+    }
     std::vector<FeatTables> host(1);
     FeatTables& t = host[0];
     std::memset(&t, 0, sizeof(t));
@@ -538,7 +552,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
 
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
-    f->nfeat = NMEL + 2 * NMFCC + (cfg->use_delta_delta ? NMFCC : 0);
+    f->nbase = cfg->use_mfcc ? NMEL + 2 * NMFCC + (cfg->use_delta_delta ? NMFCC : 0) : NMEL;
+    f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
+    f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
+    for (int i = 0; i < 18; ++i) f->contrast.edges[i] = cfg->contrast_edges[i];
     f->d_tables = nullptr;
     f->d_win_full = nullptr;
     std::vector<float> hann(NFFT);   // torch.hann_window(n_fft, periodic=True)
@@ -583,11 +600,14 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 bool featurizer_stem_fusable(const cough_featurizer* f) {
-    return f->nfeat == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+    return f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+}
+size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips) {
+    return f->contrast.n_bands > 0 && n_clips > 0 ? contrast_workspace_bytes(n_clips) : 0;
 }
 
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
-                     int flags, const StemFuse* stem, hipStream_t stream) {
+                     int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace, size_t workspace_bytes) {
     COUGH_REQUIRE(f && d_wav && (d_feat || stem), COUGH_EINVAL, "cough_featurize: NULL argument");
     COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0");
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
@@ -596,21 +616,36 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
                   "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
+    const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
     const StemFuse none{nullptr, nullptr, nullptr};
     if (stem)
         hipLaunchKernelGGL((featurize_kernel<false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, 0, *stem);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
     else if (f->cfg.use_pre_emphasis)
         hipLaunchKernelGGL((featurize_kernel<true, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, f->cfg.use_pcen, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
     else
         hipLaunchKernelGGL((featurize_kernel<false, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, f->cfg.use_delta_delta, f->cfg.use_pcen, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
     COUGH_HIP_CHECK(hipGetLastError());
+    if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)
+        return launch_contrast(featurizer_stft_view(f), f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase,
+                               n_clips, norm, d_workspace, workspace_bytes, stream);
     return COUGH_OK;
 }
 }  // namespace cough
+
+extern "C" size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips) {
+    return f ? cough::featurizer_workspace_bytes(f, n_clips) : 0;
+}
+
+extern "C" int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,
+                                  int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    COUGH_REQUIRE(d_feat, COUGH_EINVAL, "cough_featurize_ws: NULL argument");
+    return cough::launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, nullptr,
+                                   static_cast<hipStream_t>(stream), d_workspace, workspace_bytes);
+}
 
 extern "C" int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                                float* d_feat, int n_clips, int flags, void* stream) {

@@ -18,7 +18,9 @@ struct StemFuse {
 
 // featurize.hip: d_feat may be nullptr when `stem` is given (features not materialised)
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
-                     int flags, const StemFuse* stem, hipStream_t stream);
+                     int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace = nullptr,
+                     size_t workspace_bytes = 0);
+size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
 int featurizer_num_features(const cough_featurizer* f);
 bool featurizer_stem_fusable(const cough_featurizer* f);   // shipped 90-row layout, no pre-emphasis, no PCEN
 
@@ -30,6 +32,15 @@ struct StftView {
     const float2* tw512;     // [128] W512^k
 };
 StftView featurizer_stft_view(const cough_featurizer* f);
+// spectrogram.hip: spectral-contrast + centroid rows [row0, row0 + n_bands + 1) of d_feat ([n][nfeat][101])
+struct ContrastCfg {
+    int n_bands;
+    int edges[18];
+};
+size_t contrast_workspace_bytes(int n_clips);
+int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
+                    int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
+                    hipStream_t stream);
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream);
 

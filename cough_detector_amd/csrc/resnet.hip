@@ -1232,7 +1232,7 @@ extern "C" size_t cough_pipeline_workspace_bytes(const cough_featurizer* f, cons
     const int H = featurizer_num_features(f), W = cough_featurizer_num_frames(f);
     size_t b = cough_resnet_workspace_bytes(m, n_clips, H, W);
     if (!can_fuse_stem(f, m)) b += align256(size_t(n_clips) * H * W * sizeof(float));   // feature scratch
-    return b;
+    return b + align256(featurizer_workspace_bytes(f, n_clips));                          // spectral-contrast scratch
 }
 
 extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_resnet* m, const float* d_wav,
@@ -1259,8 +1259,12 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
         if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
         return forward_impl<bf16_t>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
     }
-    float* feat = d_feat ? d_feat : reinterpret_cast<float*>(ws + cough_resnet_workspace_bytes(m, n_clips, H, W));
-    if (int e = launch_featurize(f, d_wav, wav_stride, feat, n_clips, flags, nullptr, st)) return e;
+    const size_t net_bytes = cough_resnet_workspace_bytes(m, n_clips, H, W);
+    const size_t feat_bytes = align256(size_t(n_clips) * H * W * sizeof(float));
+    float* feat = d_feat ? d_feat : reinterpret_cast<float*>(ws + net_bytes);
+    if (int e = launch_featurize(f, d_wav, wav_stride, feat, n_clips, flags, nullptr, st, ws + net_bytes + feat_bytes,
+                                 featurizer_workspace_bytes(f, n_clips)))
+        return e;
     if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
     if (m->esize == 4) return forward_impl<float>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
     return forward_impl<bf16_t>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);

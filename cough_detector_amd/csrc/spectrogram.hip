@@ -209,6 +209,148 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spectral contrast + centroid rows (AudioPreprocessor.extract_spectral_contrast, preprocessing.py:242-303), out of
+// the two spectrograms the STFT kernel above leaves in a workspace.  One 128-thread workgroup per clip, thread =
+// frame.  Per band: its rows go to LDS, then each frame ranks its bins (rank = number of smaller values, ties by
+// index -- the position torch.sort would give) and sums the ranks >= top_idx and < bot_idx: the means of the
+// reference's sorted slices without sorting.  An empty top slice (one-bin band) divides 0 by 0, as the reference's
+// mean of an empty tensor does, and the z-score over all rows then turns every row into NaN, as in the reference.
+constexpr int CT_THREADS = 128, CT_MAX_BINS = 128;
+static_assert(CT_THREADS >= NFRAMES, "thread = frame");
+
+__device__ __forceinline__ float ct_block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1];
+}
+__device__ __forceinline__ float ct_block_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(red[0], red[1]);
+}
+
+__global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __restrict__ power,
+                                                             const float* __restrict__ magn,
+                                                             const float* __restrict__ wav, long long wav_stride,
+                                                             float* __restrict__ feat, int nfeat, int row0,
+                                                             ContrastCfg cfg, int normalize) {
+    __shared__ float band[CT_MAX_BINS * NFRAMES];
+    __shared__ float cr[(COUGH_MAX_CONTRAST_BANDS + 1) * NFRAMES];
+    __shared__ float red[2];
+    const int tid = threadIdx.x;
+    const long long clip = blockIdx.x;
+    const float* P = power + clip * (long long)NFREQ * NFRAMES;
+    const float* M = magn + clip * (long long)NFREQ * NFRAMES;
+    const int nb_rows = cfg.n_bands + 1;
+
+    // normalize() (preprocessing.py:199-212) scales the waveform by 1/peak, i.e. the power by 1/peak^2; the
+    // centroid is a ratio and does not change
+    float scale = 1.0f;
+    if (normalize) {
+        const float* x = wav + clip * wav_stride;
+        float m = 0.f;
+        for (int i = tid; i < NS / 4; i += CT_THREADS) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        m = ct_block_max(m, red, tid);
+        if (m > 0.f) {
+            const float inv = 1.0f / m;
+            scale = inv * inv;
+        }
+    }
+    for (int i = 0; i < cfg.n_bands; ++i) {
+        int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
+        if (high <= low) high = low + 1;
+        if (high > NFREQ) high = NFREQ;
+        const int nb = high - low;
+        __syncthreads();
+        for (int idx = tid; idx < nb * NFRAMES; idx += CT_THREADS) band[idx] = P[low * NFRAMES + idx] * scale;
+        __syncthreads();
+        if (tid < NFRAMES) {
+            int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
+            if (top_idx < 1) top_idx = 1;
+            if (bot_idx < 1) bot_idx = 1;
+            float top = 0.f, bot = 0.f;
+            for (int e = 0; e < nb; ++e) {
+                const float v = band[e * NFRAMES + tid];
+                int rank = 0;
+                for (int q = 0; q < nb; ++q) {
+                    const float u = band[q * NFRAMES + tid];
+                    rank += (u < v || (u == v && q < e)) ? 1 : 0;
+                }
+                if (rank >= top_idx) top += v;
+                if (rank < bot_idx) bot += v;
+            }
+            const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
+            const float valleys = bot / float(bot_idx);
+            cr[i * NFRAMES + tid] = log1pf(peaks) - log1pf(valleys);
+        }
+    }
+    if (tid < NFRAMES) {
+        // torchaudio.functional.spectral_centroid: freqs = linspace(0, sr // 2, 257) = k * 31.25 exactly
+        float num = 0.f, den = 0.f;
+        for (int k = 0; k < NFREQ; ++k) {
+            const float m = M[k * NFRAMES + tid];
+            num += (31.25f * float(k)) * m;
+            den += m;
+        }
+        cr[cfg.n_bands * NFRAMES + tid] = (num / den) / 8000.0f;   // / (sample_rate / 2), :297
+    }
+    __syncthreads();
+    // (contrast - mean) / (std + 1e-8) over all rows, std unbiased (:300)
+    const int total = nb_rows * NFRAMES;
+    float ls = 0.f;
+    for (int i = tid; i < total; i += CT_THREADS) ls += cr[i];
+    const float mean = ct_block_sum(ls, red, tid) / float(total);
+    float lq = 0.f;
+    for (int i = tid; i < total; i += CT_THREADS) {
+        const float d = cr[i] - mean;
+        lq += d * d;
+    }
+    const float sd = sqrtf(ct_block_sum(lq, red, tid) / float(total - 1));
+    const float rden = 1.0f / (sd + 1e-8f);
+    float* o = feat + (clip * nfeat + row0) * (long long)NFRAMES;
+    for (int i = tid; i < total; i += CT_THREADS) o[i] = (cr[i] - mean) * rden;
+}
+
+constexpr int CT_SUB_BATCH = 1024;   // clips per workspace fill: 2 x 1024 x 103 828 B = 213 MB
+
+}  // namespace
+
+size_t contrast_workspace_bytes(int n_clips) {
+    const size_t sub = n_clips < CT_SUB_BATCH ? n_clips : CT_SUB_BATCH;
+    return 2 * ((sub * NFREQ * NFRAMES * sizeof(float) + 255) & ~size_t(255));
+}
+
+int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
+                    int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+    COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
+                  "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL, "workspace must be 256-byte aligned");
+    const size_t half = contrast_workspace_bytes(n_clips) / 2;
+    float* pw = static_cast<float*>(d_workspace);
+    float* mg = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + half);
+    for (int c0 = 0; c0 < n_clips; c0 += CT_SUB_BATCH) {
+        const int nc = n_clips - c0 < CT_SUB_BATCH ? n_clips - c0 : CT_SUB_BATCH;
+        const float* w = d_wav + (long long)c0 * wav_stride;
+        if (int e = launch_stft(v, w, wav_stride, pw, nc, 0, stream)) return e;
+        if (int e = launch_stft(v, w, wav_stride, mg, nc, COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW, stream)) return e;
+        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), 0, stream, pw, mg, w, wav_stride,
+                           d_feat + (long long)c0 * nfeat * NFRAMES, nfeat, row0, cfg, normalize);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    return COUGH_OK;
+}
+
+namespace {
 }  // namespace
 
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,

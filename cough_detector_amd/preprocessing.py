@@ -11,12 +11,15 @@ Differences a caller can observe:
   passes, or "cuda"); compute is always on the MI355X -- there is no CPU fallback.
 * ``extract_features`` additionally accepts ``(B, N)`` / ``(B, 1, N)`` batches and returns
   ``(B, F, T)`` with the reference's per-clip reduction semantics.
-* Flag combinations the HIP path does not implement (PCEN, spectral contrast, ``use_mfcc=False``,
-  other STFT geometries, resampling) raise ``ValueError`` instead of changing the layout.
+* Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
+  spectral contrast + centroid); other STFT geometries raise ``ValueError`` instead of changing the layout.
+* ``use_spectral_contrast=True`` with 5 or more bands (the constructor default is 6) yields NaN rows exactly as
+  the reference does (its first band is one bin wide, ``src/preprocessing.py:272-290``); a warning says so.
 """
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import List, Optional, Tuple
 
 import torch
@@ -73,17 +76,16 @@ class AudioPreprocessor:
         self.n_contrast_bands = n_contrast_bands
         self.device = device
 
-        unsupported = []
-        if use_spectral_contrast:
-            unsupported.append("use_spectral_contrast=True")
-        if not use_mfcc:
-            unsupported.append("use_mfcc=False")
-        if unsupported:
-            raise ValueError(
-                "AudioPreprocessor: " + ", ".join(unsupported) + " is not implemented on the MI355X path; the "
-                "shipped configuration (src/train.py:264-287) is use_mfcc=True, use_pcen=False, "
-                "use_spectral_contrast=False (the reference's spectral-contrast rows are NaN by construction: its "
-                "first band is a single bin whose top-20% slice is empty)")
+        if use_spectral_contrast and not 1 <= n_contrast_bands <= _lib.MAX_CONTRAST_BANDS:
+            raise ValueError(f"AudioPreprocessor: n_contrast_bands={n_contrast_bands}: the MI355X path takes "
+                             f"1..{_lib.MAX_CONTRAST_BANDS}")
+        if use_spectral_contrast and n_contrast_bands >= 5:
+            # src/preprocessing.py:272-290: band 0 is the single bin [1, 2); its "top 20 %" slice is empty, the mean of
+            # an empty tensor is NaN, and the z-score at :300 spreads it over all n_contrast_bands + 1 rows.
+            warnings.warn(f"use_spectral_contrast=True with n_contrast_bands={n_contrast_bands}: the reference's "
+                          "spectral-contrast rows are NaN by construction for 5 or more bands (its first band is one "
+                          "bin wide); this implementation reproduces them. Use use_spectral_contrast=False (the "
+                          "shipped configuration, src/train.py:264-287) or n_contrast_bands <= 4.", stacklevel=2)
         if (sample_rate, n_fft, hop_length, win_length, n_mels, n_mfcc, self.segment_samples) != \
                 (16000, 512, 160, 400, 64, 13, 16000):
             raise ValueError("AudioPreprocessor: the MI355X path implements sample_rate=16000, n_fft=512, "
@@ -94,6 +96,7 @@ class AudioPreprocessor:
         self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
         self._dct = _tables.dct_matrix(n_mfcc, n_mels)
         self._handle: Optional[C.c_void_p] = None
+        self._ws: Optional[torch.Tensor] = None     # spectrogram scratch of the spectral-contrast rows
         self._resamplers = {}
 
     # ------------------------------------------------------------------ native handle
@@ -104,7 +107,12 @@ class AudioPreprocessor:
             cfg = _lib.FeatConfig(self.sample_rate, self.n_fft, self.hop_length, self.win_length, self.n_mels,
                                   self.n_mfcc, self.segment_samples, int(bool(self.use_pre_emphasis)),
                                   float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)),
-                                  int(bool(self.use_pcen)))
+                                  int(bool(self.use_pcen)), int(bool(self.use_mfcc)),
+                                  int(bool(self.use_spectral_contrast)), int(self.n_contrast_bands))
+            if self.use_spectral_contrast:
+                edges = _tables.contrast_band_edges(self.n_contrast_bands, self.n_fft // 2 + 1)
+                for k, e in enumerate(edges):
+                    cfg.contrast_edges[k] = int(e)
             h = C.c_void_p()
             _lib.check(lib.cough_featurizer_create(C.byref(h), C.byref(cfg), _lib.fptr(self._window),
                                                    _lib.fptr(self._mel_fb), _lib.fptr(self._dct)),
@@ -209,9 +217,16 @@ class AudioPreprocessor:
             return out
         stream = torch.cuda.current_stream(dev).cuda_stream
         stride = w.stride(0) if b > 1 else self.segment_samples
-        _lib.check(_lib.load().cough_featurize(self._native(), w.data_ptr(), stride, out.data_ptr(), b,
-                                               _lib.FEAT_NORMALIZE if normalize else 0, stream),
-                   "cough_featurize")
+        lib, h = _lib.load(), self._native()
+        need = lib.cough_featurizer_workspace_bytes(h, b)      # non-zero only with spectral contrast
+        ws = None
+        if need:
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = self._ws
+        _lib.check(lib.cough_featurize_ws(h, w.data_ptr(), stride, out.data_ptr(), b,
+                                          _lib.FEAT_NORMALIZE if normalize else 0,
+                                          ws.data_ptr() if need else None, need, stream), "cough_featurize_ws")
         return out
 
     def spectrogram_batch(self, waveforms: torch.Tensor, power: float = 2.0, full_window: bool = False,
@@ -259,7 +274,15 @@ class AudioPreprocessor:
         return self.extract_features(waveform)[:, :self.n_mels]
 
     def extract_mfcc(self, waveform: torch.Tensor) -> torch.Tensor:
+        if not self.use_mfcc:
+            raise ValueError("extract_mfcc: this preprocessor was built with use_mfcc=False")
         return self.extract_features(waveform)[:, self.n_mels:self.n_mels + self.n_mfcc]
+
+    def extract_spectral_contrast(self, waveform: torch.Tensor) -> torch.Tensor:
+        """(1, N) -> (1, n_contrast_bands + 1, T): the rows src/preprocessing.py:242-303 appends."""
+        if not self.use_spectral_contrast:
+            raise ValueError("extract_spectral_contrast: this preprocessor was built with use_spectral_contrast=False")
+        return self.extract_features(waveform)[:, -(self.n_contrast_bands + 1):]
 
     def process(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
         """resample -> mono -> normalize -> pad/trim -> features (normalize fused into the kernel:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COUGH_AMD_ABI_VERSION 1
+#define COUGH_AMD_ABI_VERSION 2
 
 #define COUGH_OK 0
 #define COUGH_EINVAL 1        /* bad argument (NULL, negative size, misaligned pointer) */
@@ -46,6 +46,7 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
  * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for the shipped
  * flags (/root/reference/src/train.py:264-287).  Output row order as the reference
  * concatenates (:456-487): mel[0:n_mels], MFCC, delta, (delta-delta). */
+#define COUGH_MAX_CONTRAST_BANDS 16
 typedef struct cough_feat_config {
     int sample_rate;       /* 16000 */
     int n_fft;             /* 512 */
@@ -58,6 +59,13 @@ typedef struct cough_feat_config {
     float pre_emphasis_coef;
     int use_delta_delta;   /* preprocessing.py:471-474 */
     int use_pcen;          /* preprocessing.py:305-340, :400-404: mel rows = min-max normalised PCEN instead of log-mel */
+    int use_mfcc;          /* preprocessing.py:458-474: 0 -> mel rows only (no MFCC / delta rows) */
+    int use_spectral_contrast; /* preprocessing.py:242-303, :476-480: n_contrast_bands + 1 extra rows (needs a workspace:
+                                * cough_featurize_ws).  NB the reference's rows are all NaN for n_contrast_bands >= 5
+                                * (its first band is one bin whose "top 20 %" slice is empty); this library reproduces
+                                * that. */
+    int n_contrast_bands;  /* 1..COUGH_MAX_CONTRAST_BANDS */
+    int contrast_edges[COUGH_MAX_CONTRAST_BANDS + 2]; /* torch.logspace(0, log10(n_fft/2+1), n_bands+2).int(), :267-268 */
 } cough_feat_config;
 
 typedef struct cough_featurizer cough_featurizer;
@@ -78,6 +86,14 @@ int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_ti
  * All reductions (peak, top_db floor, MFCC mean/std) are per clip. */
 int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                     float* d_feat, int n_clips, int flags, void* stream);
+
+/* Same, for configurations that need scratch memory (use_spectral_contrast: two spectrograms of a sub-batch).
+ * cough_featurizer_workspace_bytes is 0 for every other configuration, and cough_featurize then equals
+ * cough_featurize_ws(..., NULL, 0, ...); cough_featurize on a configuration that needs scratch returns
+ * COUGH_EWORKSPACE.  d_workspace: device memory, 256-byte aligned, owned by the caller. */
+size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
+int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,
+                       int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Stand-alone STFT: T.Spectrogram(n_fft=512, win_length=400, hop_length=160, power=2.0) of
  * /root/reference/src/preprocessing.py:131-136 (the "STFT stage" on its own; cough_featurize never

@@ -27,8 +27,10 @@ here                   reference call site -> torchaudio algorithm restated
 from __future__ import annotations
 
 import math
+import warnings
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 SAMPLE_RATE = 16000
@@ -224,16 +226,70 @@ def extract_mfcc(waveform: torch.Tensor, fb=None, dct=None) -> torch.Tensor:
     return (mfcc - mfcc.mean()) / (mfcc.std() + 1e-8)
 
 
+def contrast_band_edges(n_bands: int = 6, n_freq: int = N_FFT // 2 + 1) -> List[int]:
+    """preprocessing.py:267-268: ``torch.logspace(0, log10(n_freq), n_bands + 2).int()`` clamped to [0, n_freq]."""
+    edges = torch.logspace(0, float(np.log10(n_freq)), n_bands + 2).int()
+    return torch.clamp(edges, 0, n_freq).tolist()
+
+
+def spectral_centroid(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, n_fft: int = N_FFT,
+                      hop: int = HOP) -> torch.Tensor:
+    """torchaudio.functional.spectral_centroid as T.SpectralCentroid(sample_rate, n_fft, hop_length) calls it
+    (preprocessing.py:137-141): win_length defaults to n_fft (Hann(512), not the featuriser's Hann(400)), pad 0,
+    magnitude spectrogram; ``(freqs * |X|).sum(freq) / |X|.sum(freq)`` with freqs = linspace(0, sr // 2, 257)."""
+    spec = stft_power(waveform, n_fft=n_fft, hop=hop, win=n_fft, power=1.0)          # (..., 257, T)
+    freqs = torch.linspace(0, sample_rate // 2, steps=1 + n_fft // 2).reshape(-1, 1)
+    return (freqs * spec).sum(dim=-2) / spec.sum(dim=-2)
+
+
+def extract_spectral_contrast(waveform: torch.Tensor, n_bands: int = 6, sample_rate: int = SAMPLE_RATE) -> torch.Tensor:
+    """preprocessing.py:242-303, statement by statement: (1, N) -> (1, n_bands + 1, T).
+
+    With the default n_bands = 6 (and any n_bands >= 5) the first band is the single bin [1, 2): ``top_idx =
+    max(1, int(1 * 0.8)) = 1`` makes ``sorted_band[:, 1:, :]`` empty, its mean is NaN, and the global z-score at
+    the end spreads the NaN over every row.  The restatement keeps that behaviour."""
+    spec = stft_power(waveform)                                                       # T.Spectrogram(power=2.0)
+    n_freq, n_time = spec.shape[1], spec.shape[2]
+    band_edges = contrast_band_edges(n_bands, n_freq)
+    contrast = torch.zeros(1, n_bands + 1, n_time)
+    for i in range(n_bands):
+        low, high = band_edges[i], band_edges[i + 1]
+        if high <= low:
+            high = low + 1
+        if high > n_freq:
+            high = n_freq
+        band = spec[:, low:high, :]
+        if band.shape[1] > 0:
+            sorted_band, _ = torch.sort(band, dim=1)
+            n_bins = sorted_band.shape[1]
+            top_idx = max(1, int(n_bins * 0.8))
+            bot_idx = max(1, int(n_bins * 0.2))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                                        # mean of an empty slice
+                peaks = sorted_band[:, top_idx:, :].mean(dim=1)
+            valleys = sorted_band[:, :bot_idx, :].mean(dim=1)
+            contrast[:, i, :] = torch.log1p(peaks) - torch.log1p(valleys)
+    centroid = spectral_centroid(waveform, sample_rate) / (sample_rate / 2)
+    contrast[:, -1, :centroid.shape[1]] = centroid
+    return (contrast - contrast.mean()) / (contrast.std() + 1e-8)
+
+
 def extract_features(waveform: torch.Tensor, use_pre_emphasis: bool = False, pre_emphasis_coef: float = 0.97,
-                     use_delta_delta: bool = False, use_pcen: bool = False, fb=None, dct=None) -> torch.Tensor:
-    """F8 -- preprocessing.py:432-489: (1, N) -> (1, 90 [or 103], T)."""
+                     use_delta_delta: bool = False, use_pcen: bool = False, fb=None, dct=None,
+                     use_mfcc: bool = True, use_spectral_contrast: bool = False,
+                     n_contrast_bands: int = 6) -> torch.Tensor:
+    """F8 -- preprocessing.py:432-489: (1, N) -> (1, 90 [or 103, +7 with spectral contrast], T)."""
     w = pre_emphasis(waveform, pre_emphasis_coef) if use_pre_emphasis else waveform
     mel = extract_mel_spectrogram(w, fb, use_pcen)
-    mfcc = extract_mfcc(w, fb, dct)
-    delta = compute_deltas(mfcc)
-    feats = [mel, mfcc, delta]
-    if use_delta_delta:
-        feats.append(compute_deltas(delta))
+    feats = [mel]
+    if use_mfcc:
+        mfcc = extract_mfcc(w, fb, dct)
+        delta = compute_deltas(mfcc)
+        feats += [mfcc, delta]
+        if use_delta_delta:
+            feats.append(compute_deltas(delta))
+    if use_spectral_contrast:
+        feats.append(extract_spectral_contrast(waveform, n_contrast_bands))   # from the un-emphasised signal (:476-478)
     t = min(f.shape[2] for f in feats)
     return torch.cat([f[:, :, :t] for f in feats], dim=1)
 

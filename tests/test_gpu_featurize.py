@@ -225,3 +225,54 @@ def test_stft_stage_full_batch_parseval(pre):
     rel = ((lhs.double() - rhs).abs() / (rhs + 1e-12 * rhs.max())).max()
     assert float(rel) < 1e-4
     assert torch.equal(p[:64], p[-64:])                                  # deterministic across workgroups
+
+
+@pytest.mark.parametrize("n_bands", [1, 2, 3, 4])
+def test_spectral_contrast_rows_against_oracle(n_bands):
+    """use_spectral_contrast=True (preprocessing.py:242-303, :476-480): band contrast + centroid rows, z-scored
+    together, appended after the MFCC block; computed from the un-emphasised, optionally normalised signal."""
+    flags = dict(use_pcen=False, use_pre_emphasis=True, use_delta_delta=True, use_spectral_contrast=True,
+                 n_contrast_bands=n_bands)
+    p = cda.AudioPreprocessor(device="cuda", **flags)
+    w = synth_batch(500, 20)
+    got = p.featurize_batch(w.cuda(), normalize=True).cpu()
+    nrow = 64 + 39 + n_bands + 1
+    assert got.shape == (20, nrow, 101) and p.get_num_features() == nrow
+    ref = ofeat.extract_features_batch(w, normalize_first=True, use_pre_emphasis=True, use_delta_delta=True,
+                                       use_spectral_contrast=True, n_contrast_bands=n_bands)
+    mel, rel = feature_errors(got[:, :103], ref[:, :103])
+    assert mel < FEAT_TOL and rel < FEAT_TOL                       # the rows in front are untouched
+    c_got, c_ref = got[:, 103:], ref[:, 103:]
+    assert torch.isfinite(c_got).all()
+    # rows are z-scored to unit variance over the block; relative to max(|ref|, 0.1) so that the zero crossings of
+    # the z-score (|ref| ~ 1e-3, where one ulp of the un-normalised value is already 3e-4 of it) do not set the bar
+    err = float(((c_got - c_ref).abs() / c_ref.abs().clamp_min(0.1)).max())
+    abs_err = float((c_got - c_ref).abs().max())
+    print(f"contrast n_bands={n_bands}: rel err {err:.2e}, abs err {abs_err:.2e}")
+    assert err < FEAT_TOL and abs_err < 1e-5
+    one = p.extract_spectral_contrast(w[:1])                      # the reference's method name, (1, N) -> (1, n+1, T)
+    assert one.shape == (1, n_bands + 1, 101)
+
+
+def test_reference_default_constructor_reproduces_nan_rows():
+    """AudioPreprocessor() -- PCEN, pre-emphasis, delta-delta, 6 contrast bands = 110 rows.  The reference's 7
+    contrast rows are NaN for every input (one-bin first band); so are ours, and the 103 rows in front match."""
+    with pytest.warns(UserWarning, match="NaN by construction"):
+        p = cda.AudioPreprocessor(device="cuda")
+    w = synth_batch(600, 6)
+    got = p.extract_features(w.cuda()).cpu()
+    ref = ofeat.extract_features_batch(w, use_pre_emphasis=True, use_delta_delta=True, use_pcen=True,
+                                       use_spectral_contrast=True, n_contrast_bands=6)
+    assert got.shape == ref.shape == (6, 110, 101)
+    assert torch.isnan(ref[:, 103:]).all() and torch.isnan(got[:, 103:]).all()
+    mel, rel = feature_errors(got[:, :103], ref[:, :103])
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def test_mel_only_configuration():
+    p = cda.AudioPreprocessor(device="cuda", **{**SHIPPED, "use_mfcc": False})
+    w = synth_batch(700, 8)
+    got = p.extract_features(w.cuda()).cpu()
+    ref = ofeat.extract_features_batch(w, use_mfcc=False)
+    assert got.shape == ref.shape == (8, 64, 101)
+    assert float((got - ref).abs().max()) < FEAT_TOL

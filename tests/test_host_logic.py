@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cough_amd_abi_version() == 1
+    assert lib.cough_amd_abi_version() == 2
     assert lib.cough_amd_arch() == b"gfx950"
 
 
 def test_ctypes_structs_match_header_layout():
-    assert ctypes.sizeof(_lib.FeatConfig) == 11 * 4
+    assert ctypes.sizeof(_lib.FeatConfig) == (14 + _lib.MAX_CONTRAST_BANDS + 2) * 4   # 14 scalars + contrast_edges[18]
     assert ctypes.sizeof(_lib.ConvBN) == 6 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_lib.ResNetWeights) == (7 * 6 + 2) * 8 + 8
 
@@ -52,8 +52,13 @@ def test_preprocessor_interface_and_errors():
     p = cda.AudioPreprocessor(**SHIPPED)
     assert p.get_num_features() == 90 and p.get_expected_time_frames() == 101
     assert cda.AudioPreprocessor(**{**SHIPPED, "use_delta_delta": True}).get_num_features() == 103
-    with pytest.raises(ValueError, match="use_spectral_contrast"):
-        cda.AudioPreprocessor()                              # reference defaults include spectral contrast
+    with pytest.warns(UserWarning, match="NaN by construction"):
+        full = cda.AudioPreprocessor()                       # reference defaults: PCEN, delta-delta, 6 contrast bands
+    assert full.get_num_features() == 110                    # 64 + 3 * 13 + 7, README "110 features"
+    assert cda.AudioPreprocessor(**{**SHIPPED, "use_mfcc": False}).get_num_features() == 64
+    assert cda.AudioPreprocessor(**{**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 4}).get_num_features() == 95
+    with pytest.raises(ValueError, match="n_contrast_bands"):
+        cda.AudioPreprocessor(**{**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 40})
     assert cda.AudioPreprocessor(use_spectral_contrast=False, use_delta_delta=False).get_num_features() == 90   # PCEN on
     with pytest.raises(ValueError, match="n_fft"):
         cda.AudioPreprocessor(n_fft=1024, **SHIPPED)

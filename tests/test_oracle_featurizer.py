@@ -2,6 +2,8 @@
 re-derivation, third-party table cross-checks, analytic known answers, golden regression."""
 import zlib
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -151,3 +153,28 @@ def test_resampler_restatement_properties():
     t2 = torch.arange(16000) / 16000.0
     assert (r[100:-100] - torch.sin(2 * torch.pi * 1000 * t2)[100:-100]).abs().max() < 2e-3
     assert F.process(x[:, :20000], 44100).shape == (1, 90, 101)       # short clip is centre-padded
+
+
+def test_spectral_contrast_restatement_band_edges_and_nan_rule():
+    """preprocessing.py:242-303.  Edges are the reference's own torch expression; with >= 5 bands the first band is
+    the single bin [1, 2), its top-20 % slice is empty and every row becomes NaN; with <= 4 bands all rows are
+    finite and z-scored over the whole (n_bands + 1, T) block."""
+    assert F.contrast_band_edges(6) == [1, 2, 4, 10, 23, 52, 116, 256]
+    assert F.contrast_band_edges(4)[:5] == [1, 3, 9, 27, 84]
+    rng = np.random.default_rng(5)
+    w = torch.from_numpy(rng.standard_normal((1, 16000)).astype(np.float32) * 0.1)
+    for n in (5, 6, 8):
+        assert torch.isnan(F.extract_spectral_contrast(w, n)).all()
+    for n in (1, 2, 3, 4):
+        c = F.extract_spectral_contrast(w, n)
+        assert c.shape == (1, n + 1, 101) and torch.isfinite(c).all()
+        assert abs(float(c.mean())) < 1e-5 and abs(float(c.std()) - 1.0) < 1e-4
+    # centroid of a pure tone sits at the tone (Hann(512) window, bin-centred 1 kHz)
+    t = torch.arange(16000) / 16000.0
+    cen = F.spectral_centroid(torch.sin(2 * math.pi * 1000.0 * t)[None])
+    assert cen.shape == (1, 101) and abs(float(cen[0, 50]) - 1000.0) < 5.0
+    # rows land after the MFCC block, from the un-emphasised signal
+    f = F.extract_features(w, use_pre_emphasis=True, use_delta_delta=True, use_spectral_contrast=True, n_contrast_bands=3)
+    assert f.shape == (1, 64 + 39 + 4, 101)
+    assert torch.equal(f[:, -4:], F.extract_spectral_contrast(w, 3))
+    assert F.extract_features(w, use_mfcc=False).shape == (1, 64, 101)
