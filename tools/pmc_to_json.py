@@ -1,7 +1,7 @@
 """Turn the rocprofv3 --pmc output of tools/pmc_k1.sh into profiles/<name>.json with the gfx950
 corrections of MI355X_MICROARCH.md "HBM" applied (FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reads 1/2
 of the bytes of a coalesced stream -- confirmed for 4/8/16 B per lane by tools/calib_fetch.hip;
-WRITE_SIZE is exact).  Usage: python tools/pmc_to_json.py gpurun_out/<dir> profiles/<name>.json [batch]"""
+WRITE_SIZE is exact).  Usage: python tools/pmc_to_json.py gpurun_out/<dir> profiles/<name>.json [batch] [kernel-substring] [bytes/clip]"""
 import collections
 import csv
 import glob
@@ -11,21 +11,23 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+kern = sys.argv[4] if len(sys.argv) > 4 else "featurize"
+bytes_per_clip = int(sys.argv[5]) if len(sys.argv) > 5 else 100360
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "featurize" in r["Kernel_Name"]:
+        if kern in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 per = {k: v / n for k, (v, n) in agg.items()}
 fetch_b = per["FETCH_SIZE"] * 1024 * 2
 write_b = per["WRITE_SIZE"] * 1024
-out = {"kernel": "featurize_kernel", "clips_per_launch": batch, "normalize": True,
+out = {"kernel": kern + "_kernel", "clips_per_launch": batch, "normalize": True,
        "counters_per_launch": per,
        "corrections": "FETCH_SIZE[KiB]*1024*2 (gfx950 half-count, calibrated), WRITE_SIZE[KiB]*1024",
        "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
        "traffic_bytes_per_launch": fetch_b + write_b,
-       "algorithmic_bytes_per_launch": batch * 100360,
-       "traffic_over_algorithmic": (fetch_b + write_b) / (batch * 100360)}
+       "algorithmic_bytes_per_launch": batch * bytes_per_clip,
+       "traffic_over_algorithmic": (fetch_b + write_b) / (batch * bytes_per_clip)}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "traffic_over_algorithmic")}))
