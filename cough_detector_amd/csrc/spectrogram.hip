@@ -8,15 +8,14 @@
 // The fused featuriser (featurize.hip) never materialises the spectrogram; this kernel is the same FFT with all
 // 257 bins formed and stored.  Algorithmic bytes per clip: 64 000 read + 257*101*4 = 103 828 written.
 //
-// Work item = (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames); a persistent grid of 4-wave
-// workgroups (three resident per CU) walks the items.  A wave transforms 4 frames at a time (16 lanes each): lane
-// j of a frame ends up with Z[j+16*k2]; with its partner's Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and
-// X[256-k] -- conj(E - W^k O) -- so every bin 0..256 comes out of the same 8 butterflies.  The (bin, time) output
-// is time-minor, so the chunk's powers are staged in LDS and flushed as ~100-byte row fragments; the stores drain
-// while the workgroup transforms its next item (a workgroup that ended after each flush would hold its LDS until
-// the stores are acknowledged).  The four chunks of a clip are taken in the same sweep by workgroups 8 ids apart:
-// same XCD (ids are dealt round-robin over the 8 XCDs), same time, so the fragments of one 404-byte row meet in
-// that XCD's L2 and leave as whole lines (WRITE_SIZE = 1.07x the algorithmic bytes).
+// One 4-wave workgroup per (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames), three resident per
+// CU.  A wave transforms 4 frames at a time (16 lanes each): lane j of a frame ends up with Z[j+16*k2]; with its
+// partner's Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and X[256-k] -- conj(E - W^k O) -- so every bin 0..256
+// comes out of the same 8 butterflies.  The (bin, time) output is time-minor, so the chunk's powers are staged in
+// LDS and flushed as ~100-byte row fragments.  The four chunks of a clip sit on workgroup ids 8 apart: same XCD
+// (ids are dealt round-robin over the 8 XCDs), dispatched together, so the fragments of one 404-byte row meet in
+// that XCD's L2 and leave as whole lines: WRITE_SIZE = 1.004x the algorithmic bytes (1.34x with one workgroup
+// per clip flushing chunk after chunk; 1.29x with a persistent grid, whose sibling workgroups drift apart).
 #include "common.h"
 #include "fft256.h"
 #include "internal.h"
@@ -42,22 +41,13 @@ constexpr size_t LDS_TOTAL = LDS_XCH + LDS_TW + LDS_PW;
 static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
 static_assert(LDS_XCH % 16 == 0 && LDS_TW % 16 == 0, "float2 table and staging rows start 16-byte aligned");
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, and a fence is
-// a vmcnt(0) -- it would wait for the samples fetched ahead and for the previous flush's stores.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // FULLWIN: all 512 window taps are live (Hann(512)); otherwise taps [0,56) and [456,512) are zero (Hann(400)
 // centred in the frame) and the first / last 32-sample slabs are never loaded.
 template <bool FULLWIN, bool MAG>
 __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restrict__ wav, long long wav_stride,
                                                           float* __restrict__ out, const float* __restrict__ win,
                                                           const float2* __restrict__ tw256,
-                                                          const float2* __restrict__ tw512, int n_clips,
-                                                          int n_items) {
+                                                          const float2* __restrict__ tw512, int n_clips) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);
     float2* twl = reinterpret_cast<float2*>(smem + LDS_XCH);              // [16][XROW], 8-byte aligned (ds_read2_b64)
@@ -65,15 +55,10 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
     constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // item id i = slab * 8 + r: clip = (slab / NCHUNK) * 8 + r, chunk = slab % NCHUNK
-    auto decode = [&](int item, long long& clip, int& chunk) {
-        const int slab = item >> 3;
-        clip = (long long)(slab / NCHUNK) * 8 + (item & 7);
-        chunk = slab % NCHUNK;
-    };
-    long long clip;
-    int chunk;
-    decode(blockIdx.x, clip, chunk);
+    // workgroup id = slab * 8 + r: clip = (slab / NCHUNK) * 8 + r, chunk = slab % NCHUNK
+    const int slab = blockIdx.x >> 3;
+    const long long clip = (long long)(slab / NCHUNK) * 8 + (blockIdx.x & 7);
+    const int chunk = slab % NCHUNK;
     const int j = lane & 15, fsub = lane >> 4;
     const float2* tw_row = twl + j * XROW;
     const float2 tw_j = tw512[j];
@@ -97,8 +82,9 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
             }
         }
     };
+    if (clip >= n_clips) return;   // workgroup-uniform: the last slab of 8 clips may be partial
     float2 raw[16];
-    if (clip < n_clips) load_group(wav + clip * wav_stride, CHUNK_G0[chunk] + wave, raw);
+    load_group(wav + clip * wav_stride, CHUNK_G0[chunk] + wave, raw);
     // window taps and the W256 table arrive while the first samples are on their way from HBM
     float w_re[16], w_im[16];
 #pragma unroll
@@ -109,12 +95,7 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
     twl[(tid >> 4) * XROW + (tid & 15)] = tw256[tid];
     __syncthreads();
 
-    // clips past n_clips (last slab group only) are the last items of the workgroups that own them
-    for (int item = blockIdx.x; item < n_items && clip < n_clips; item += gridDim.x) {
-        long long nclip = n_clips;
-        int nchunk = 0;
-        if (item + (int)gridDim.x < n_items) decode(item + gridDim.x, nclip, nchunk);
-        const bool more = nclip < n_clips;                  // workgroup-uniform
+    {
         const float* x = wav + clip * wav_stride;
         const int gs = CHUNK_G0[chunk], ge = CHUNK_G0[chunk + 1];
 #pragma unroll 1
@@ -126,14 +107,8 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
             }
 #pragma unroll
             for (int n1 = N0; n1 < N1; ++n1) a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
-            // the raw registers are free: the wave's next group (of this item, else the first of the next item)
-            // starts moving now and lands during this FFT
-            {
-                const bool same = g + WAVES < ge;
-                const float* xn = same ? x : wav + nclip * wav_stride;
-                const int gn = same ? g + WAVES : CHUNK_G0[nchunk] + wave;
-                if (same || more) load_group(xn, gn, raw);
-            }
+            // the raw registers are free: the wave's second group starts moving now and lands during this FFT
+            if (g + WAVES < ge) load_group(x, g + WAVES, raw);
             dft16(a);
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
@@ -184,11 +159,8 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
             }
             wave_lds_fence();
         }
-        lds_barrier();
+        __syncthreads();
         {
-            // A fixed number of stores per thread (32 + the odd row), fully unrolled: vmcnt counts loads and stores in
-            // issue order, so the wait for the samples fetched ahead (issued before these stores) can only leave the
-            // stores in flight if their count is a compile-time constant.
             const int t0 = gs * FPW;
             const int nv = (ge * FPW < NFRAMES ? ge * FPW : NFRAMES) - t0;
             float* o = out + clip * (long long)NFREQ * NFRAMES + t0;
@@ -203,9 +175,6 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
                 if (r0 == 0) dst[256 * NFRAMES] = src[256 * PITCH];
             }
         }
-        if (more) lds_barrier();   // the staging buffer is free for the next item
-        clip = nclip;
-        chunk = nchunk;
     }
 }
 
@@ -355,23 +324,12 @@ namespace {
 
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream) {
-    static int n_cus = 0;   // same device for the life of the process (one process per GPU)
-    if (n_cus == 0) {
-        int dev = 0, cus = 0;
-        COUGH_HIP_CHECK(hipGetDevice(&dev));
-        COUGH_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cus = cus > 0 ? cus : 256;
-    }
-    const int n_items = ((n_clips + 7) / 8) * 8 * NCHUNK;
-    // resident slots, rounded down to a multiple of 8 * NCHUNK so that ids 8 apart stay on one clip's chunks
-    int slots = (n_cus * 3) / (8 * NCHUNK) * (8 * NCHUNK);
-    if (slots < 8 * NCHUNK) slots = 8 * NCHUNK;
-    const dim3 grid(n_items < slots ? n_items : slots), block(THREADS);
+    const dim3 grid(((n_clips + 7) / 8) * 8 * NCHUNK), block(THREADS);   // id = (slab * NCHUNK + chunk) * 8 + clip % 8
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const float* win = full ? v.win_full : v.win;
 #define COUGH_STFT_LAUNCH(F, M)                                                                              \
     hipLaunchKernelGGL((stft_kernel<F, M>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_spec, win, \
-                       v.tw256, v.tw512, n_clips, n_items)
+                       v.tw256, v.tw512, n_clips)
     if (full && mag) COUGH_STFT_LAUNCH(true, true);
     else if (full) COUGH_STFT_LAUNCH(true, false);
     else if (mag) COUGH_STFT_LAUNCH(false, true);
