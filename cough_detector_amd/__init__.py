@@ -2,9 +2,11 @@
 forward + sliding-window engine, behind the reference's Python call surface.  All arithmetic runs in
 hand-written HIP kernels (``csrc/``) reached through the C-ABI in ``include/cough_amd.h``."""
 from .preprocessing import AudioPreprocessor, RealtimePreprocessor, create_preprocessor
-from .model import CoughDetectorResidual, ResidualBlock, create_model, count_parameters
+from .model import (CoughDetector, CoughDetectorResidual, CoughDetectorSmall, ConvBlock, ResidualBlock, create_model,
+                    count_parameters)
 from .inference import CoughDetectorInference
 from .pipeline import CoughPipeline
 
 __all__ = ["AudioPreprocessor", "RealtimePreprocessor", "create_preprocessor", "CoughDetectorResidual",
+           "CoughDetector", "CoughDetectorSmall", "ConvBlock",
            "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference", "CoughPipeline"]

@@ -26,6 +26,7 @@ SYMBOLS = (
     "cough_spectrogram",
     "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resnet_forward", "cough_resnet_read_activation",
+    "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
     "cough_resample", "cough_ring_write", "cough_window_gather",
 )
@@ -55,6 +56,16 @@ class ResBlockWeights(C.Structure):
 
 class ResNetWeights(C.Structure):
     _fields_ = [("stem", ConvBN), ("block", ResBlockWeights * 2), ("fc_w", _FP), ("fc_b", _FP), ("bn_eps", C.c_float)]
+
+
+class CnnBlock(C.Structure):
+    _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("ksize", C.c_int), ("dw_w", _FP), ("dw_b", _FP),
+                ("conv", ConvBN), ("pool", C.c_int)]
+
+
+class CnnWeights(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("blocks", C.POINTER(CnnBlock)), ("hidden", C.c_int), ("fc1_w", _FP),
+                ("fc1_b", _FP), ("fc2_w", _FP), ("fc2_b", _FP), ("bn_eps", C.c_float)]
 
 
 _lib = None
@@ -95,6 +106,13 @@ def load() -> C.CDLL:
         lib.cough_resnet_workspace_bytes.restype = C.c_size_t
         lib.cough_resnet_forward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, C.c_size_t, vp]
         lib.cough_resnet_read_activation.argtypes = [vp, vp, i, i, i, i, vp, vp]
+        lib.cough_cnn_create.argtypes = [C.POINTER(vp), C.POINTER(CnnWeights), i]
+        lib.cough_cnn_destroy.argtypes = [vp]
+        lib.cough_cnn_destroy.restype = None
+        lib.cough_cnn_workspace_bytes.argtypes = [vp, i, i, i]
+        lib.cough_cnn_workspace_bytes.restype = C.c_size_t
+        lib.cough_cnn_forward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.cough_cnn_conv_output.argtypes = [vp, vp, i, i, i, vp, vp, C.c_size_t, vp]
         lib.cough_pipeline_workspace_bytes.argtypes = [vp, vp, i]
         lib.cough_pipeline_workspace_bytes.restype = C.c_size_t
         lib.cough_pipeline_forward.argtypes = [vp, vp, vp, ll, i, i, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]

@@ -1,0 +1,495 @@
+// Sequential conv-block classifiers for gfx950 (eval mode): CoughDetector ("standard") and CoughDetectorSmall.
+//
+// Replaces /root/reference/src/model.py:11-40 (ConvBlock), :43-141 (CoughDetector.forward / predict) and
+// :144-207 (CoughDetectorSmall.forward / predict).  Both networks are a stack of
+//     y = maxpool2?( ReLU( BN( conv(x) ) ) )        conv = 3x3 pad 1, or depthwise 3x3 pad 1 -> pointwise 1x1
+// followed by a global mean and Linear -> ReLU -> Linear.  At create time BatchNorm (running stats) is folded into
+// the conv, and a depthwise/pointwise pair -- there is nothing between the two convolutions -- is composed into
+// the dense 3x3 convolution it equals, W[n][c][tap] = Wpw[n][c] * Wdw[c][tap], b[n] = bpw[n] + sum_c Wpw[n][c]*bdw[c]
+// (in double): 9x the separable MACs, but a real dense contraction for the matrix cores instead of a
+// bandwidth-bound elementwise pass plus a skinny GEMM.  Dropout / Dropout2d are the identity in eval mode.
+//
+//   first block (Cin = 1)  cnn_first_kernel: direct f32 conv out of the (H, W) feature image, bias, ReLU, 2x2 max,
+//                          NHWC store; weights are wave-uniform (scalar loads)
+//   other blocks           cnn_conv_kernel<T, NT, POOL>: implicit GEMM on v_mfma_f32_32x32x2_f32 (T = float) or
+//                          v_mfma_f32_32x32x16_bf16, NHWC activations.  With POOL the GEMM rows are ordered
+//                          (pool window, dy, dx), so the 2x2 max is a max over 4 accumulator registers of one lane
+//                          and the un-pooled conv output never exists (floor mode: the odd last row / column is
+//                          never computed)
+//   head                   cnn_tail_kernel: mean over H x W -> Linear -> ReLU -> Linear -> softmax / argmax
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+#include "nn_common.h"
+
+namespace cough {
+namespace {
+
+// ------------------------------------------------------------------------------------------ first block
+// thread = one (pooled) output pixel, all N channels; the 4x4 (3x3) input patch sits in registers
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void cnn_first_kernel(const float* __restrict__ feat, int H, int W, int OH, int OW,
+                                                        long long n_out, const float* __restrict__ wk /* [9][N] */,
+                                                        const float* __restrict__ bias, int N, T* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_out) return;
+    const int per = OH * OW;
+    const long long b = idx / per;
+    const int rem = int(idx - b * per), oh = rem / OW, ow = rem - oh * OW;
+    constexpr int P = POOL ? 4 : 3, S = POOL ? 2 : 1;
+    const float* src = feat + b * (long long)H * W;
+    float v[P][P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int jx = 0; jx < P; ++jx) {
+            const int ih = S * oh - 1 + i, iw = S * ow - 1 + jx;
+            v[i][jx] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? src[ih * W + iw] : 0.f;
+        }
+    T* o = out + idx * N;
+    for (int n0 = 0; n0 < N; n0 += 8) {   // wk / bias addresses are wave-uniform: scalar loads
+        float res[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + u;
+            float w9[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w9[k] = wk[k * N + n];
+            float best = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < S; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < S; ++dx) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc = fmaf(v[dy + kh][dx + kw], w9[kh * 3 + kw], acc);
+                    best = fmaxf(best, acc);
+                }
+            res[u] = fmaxf(best + bias[n], 0.f);
+        }
+        if constexpr (sizeof(T) == 4) {   // 8 consecutive channels of one pixel: 32 / 16 contiguous bytes per lane
+            *reinterpret_cast<float4*>(o + n0) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4*>(o + n0 + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        } else {
+            uint4 pk;
+            pk.x = uint32_t(f2bf(res[0])) | (uint32_t(f2bf(res[1])) << 16);
+            pk.y = uint32_t(f2bf(res[2])) | (uint32_t(f2bf(res[3])) << 16);
+            pk.z = uint32_t(f2bf(res[4])) | (uint32_t(f2bf(res[5])) << 16);
+            pk.w = uint32_t(f2bf(res[6])) | (uint32_t(f2bf(res[7])) << 16);
+            *reinterpret_cast<uint4*>(o + n0) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dense blocks
+template <typename T>
+struct CnnConvArgs {
+    const T* in;      // NHWC [B][H][W][C]
+    int H, W, C, KS;  // KS = 1 or 3 (pad (KS-1)/2, stride 1)
+    const T* wp;      // [N][KS*KS*C], k = (kh*KS + kw)*C + c
+    const float* bias;
+    T* out;           // NHWC [B][OH][OW][N]
+    int OH, OW, N;
+    long long M;      // GEMM rows: B*OH*OW (x4 with POOL)
+};
+
+// K chunking (A and B use the same channel <-> k-slot map):
+//   f32 : 8 channels per chunk, four v_mfma_f32_32x32x2_f32; k-slot h of step e <-> channel 4h+e
+//   bf16: 16 channels per chunk, one v_mfma_f32_32x32x16_bf16; lane half h holds channels 8h..8h+7
+template <typename T, int NT, bool POOL>
+__global__ __launch_bounds__(256) void cnn_conv_kernel(CnnConvArgs<T> a) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const long long m0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
+    if (m0 >= a.M) return;
+    const int n_base = blockIdx.y * (NT * 32);
+    const long long m = m0 + r;
+    const bool rowok = m < a.M;
+    const long long mc = rowok ? m : 0;
+    const int per = a.OH * a.OW;
+    int b, oh, ow;   // conv output pixel of this GEMM row
+    if constexpr (POOL) {
+        const long long pix = mc >> 2;
+        const int q = int(mc & 3);
+        b = int(pix / per);
+        const int rem = int(pix - (long long)b * per), ph = rem / a.OW, pw = rem - ph * a.OW;
+        oh = 2 * ph + (q >> 1);
+        ow = 2 * pw + (q & 1);
+    } else {
+        b = int(mc / per);
+        const int rem = int(mc - (long long)b * per);
+        oh = rem / a.OW;
+        ow = rem - oh * a.OW;
+    }
+    const int pad = (a.KS - 1) >> 1, Ktot = a.KS * a.KS * a.C;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16{0};
+    const T* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.wp + (long long)(n_base + nt * 32 + r) * Ktot;
+
+    int kbase = 0;
+    for (int kh = 0; kh < a.KS; ++kh)
+        for (int kw = 0; kw < a.KS; ++kw) {
+            const int ih = oh - pad + kh, iw = ow - pad + kw;
+            const bool ok = rowok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const T* ap = a.in + (((long long)b * a.H + (ok ? ih : 0)) * a.W + (ok ? iw : 0)) * a.C;
+            if constexpr (sizeof(T) == 4) {
+                for (int c0 = 0; c0 < a.C; c0 += 8) {
+                    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) av = *reinterpret_cast<const float4*>(ap + c0 + 4 * h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 bv = *reinterpret_cast<const float4*>(wrow[nt] + kbase + c0 + 4 * h);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                    }
+                }
+            } else {
+                for (int c0 = 0; c0 < a.C; c0 += 16) {
+                    bf16x8 av = {0};
+                    if (ok) av = *reinterpret_cast<const bf16x8*>(ap + c0 + 8 * h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wrow[nt] + kbase + c0 + 8 * h);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            kbase += a.C;
+        }
+    // epilogue: accumulator register `reg` of lane (r, h) is GEMM row (reg & 3) + 8 * (reg >> 2) + 4 * h, column r
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * 32 + r;
+        const float bn = a.bias[n];
+        if constexpr (POOL) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // rows 8g + 4h .. +3 = the four positions of pool window 2g + h
+                const long long pix = (m0 >> 2) + 2 * g + h;
+                const float v = fmaxf(fmaxf(acc[nt][4 * g], acc[nt][4 * g + 1]), fmaxf(acc[nt][4 * g + 2], acc[nt][4 * g + 3]));
+                if (pix * 4 < a.M) a.out[pix * a.N + n] = from_f32<T>(fmaxf(v + bn, 0.f));
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long mo = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (mo < a.M) a.out[mo * a.N + n] = from_f32<T>(fmaxf(acc[nt][reg] + bn, 0.f));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ head
+// one workgroup per clip: thread c < C averages channel c; thread j < HID forms hidden unit j; wave 0 the logits
+template <typename T>
+__global__ __launch_bounds__(256) void cnn_tail_kernel(const T* __restrict__ act, int HW, int C, int HID,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ logits, float* __restrict__ probs,
+                                                       int* __restrict__ preds) {
+    __shared__ float v[256], hid[256];
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x;
+    if (tid < C) {
+        const T* p = act + b * (long long)HW * C + tid;
+        float s = 0.f;
+        for (int i = 0; i < HW; ++i) s += to_f32<T>(p[(long long)i * C]);
+        v[tid] = s / float(HW);
+    }
+    __syncthreads();
+    if (tid < HID) {
+        const float* wr = w1 + (long long)tid * C;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(wr[c], v[c], s);
+        hid[tid] = fmaxf(s + b1[tid], 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float l0 = 0.f, l1 = 0.f;
+        for (int jx = tid; jx < HID; jx += 64) {
+            l0 = fmaf(w2[jx], hid[jx], l0);
+            l1 = fmaf(w2[HID + jx], hid[jx], l1);
+        }
+        l0 = wave_sum(l0) + b2[0];
+        l1 = wave_sum(l1) + b2[1];
+        if (tid == 0) {
+            logits[b * 2] = l0;
+            logits[b * 2 + 1] = l1;
+            if (probs) {
+                const float mx = fmaxf(l0, l1), e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.0f / (e0 + e1);
+                probs[b * 2] = e0 * inv;
+                probs[b * 2 + 1] = e1 * inv;
+            }
+            if (preds) preds[b] = (l1 > l0) ? 1 : 0;   // argmax returns the first maximal index on ties
+        }
+    }
+}
+
+template <typename T>
+__global__ void cnn_nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int p = int(idx % HW);
+    const long long bc = idx / HW;
+    const int c = int(bc % C);
+    const long long b = bc / C;
+    out[idx] = to_f32<T>(in[(b * HW + p) * C + c]);
+}
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+}  // namespace
+}  // namespace cough
+
+struct cough_cnn {
+    struct Layer {
+        int cin, cout, ks, pool;
+        void* d_w;      // first layer: float [9][N]; others: T [N][ks*ks*cin]
+        float* d_b;
+    };
+    int dtype;
+    size_t esize;
+    std::vector<Layer> layers;
+    int feat_c, hidden;
+    float *d_w1, *d_b1, *d_w2, *d_b2;
+};
+
+namespace cough {
+namespace {
+
+struct CnnShape { int h, w, c; };
+
+// output shape of every block for an (H, W) input; false if the image vanishes
+bool cnn_shapes(const cough_cnn* m, int H, int W, std::vector<CnnShape>& out) {
+    int h = H, w = W;
+    out.clear();
+    for (const auto& l : m->layers) {
+        if (l.pool == 2) { h /= 2; w /= 2; }
+        if (h < 1 || w < 1) return false;
+        out.push_back({h, w, l.cout});
+    }
+    return true;
+}
+
+template <typename T>
+int cnn_upload(void** dst, const std::vector<T>& v) {
+    COUGH_HIP_CHECK(hipMalloc(dst, v.size() * sizeof(T)));
+    COUGH_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return COUGH_OK;
+}
+
+template <typename T>
+int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int W, float* d_logits, float* d_probs,
+                     int* d_preds, char* ws, hipStream_t st, int tap_layer, float* d_tap) {
+    std::vector<CnnShape> shp;
+    cnn_shapes(m, H, W, shp);
+    size_t buf = 0;
+    for (const auto& s : shp) buf = std::max(buf, align256(size_t(n) * s.h * s.w * s.c * m->esize));
+    T* ping[2] = {reinterpret_cast<T*>(ws), reinterpret_cast<T*>(ws + buf)};
+    const T* cur = nullptr;
+    int ch = H, cw = W;
+    for (size_t i = 0; i < m->layers.size(); ++i) {
+        const auto& l = m->layers[i];
+        const CnnShape& s = shp[i];
+        T* dst = ping[i & 1];
+        if (i == 0) {
+            const long long n_out = (long long)n * s.h * s.w;
+            const dim3 grid((unsigned)((n_out + 255) / 256));
+            if (l.pool == 2)
+                hipLaunchKernelGGL((cnn_first_kernel<T, true>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
+                                   static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
+            else
+                hipLaunchKernelGGL((cnn_first_kernel<T, false>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
+                                   static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
+        } else {
+            CnnConvArgs<T> a{};
+            a.in = cur; a.H = ch; a.W = cw; a.C = l.cin; a.KS = l.ks;
+            a.wp = static_cast<const T*>(l.d_w); a.bias = l.d_b;
+            a.out = dst; a.OH = s.h; a.OW = s.w; a.N = l.cout;
+            a.M = (long long)n * s.h * s.w * (l.pool == 2 ? 4 : 1);
+            const int nt = l.cout >= 128 ? 4 : l.cout / 32;
+            const dim3 grid((unsigned)(((a.M + 31) / 32 + 3) / 4), (unsigned)(l.cout / (32 * nt)));
+#define COUGH_CNN_LAUNCH(NT)                                                                              \
+    do {                                                                                                 \
+        if (l.pool == 2) hipLaunchKernelGGL((cnn_conv_kernel<T, NT, true>), grid, dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((cnn_conv_kernel<T, NT, false>), grid, dim3(256), 0, st, a);              \
+    } while (0)
+            if (nt == 1) COUGH_CNN_LAUNCH(1);
+            else if (nt == 2) COUGH_CNN_LAUNCH(2);
+            else COUGH_CNN_LAUNCH(4);
+#undef COUGH_CNN_LAUNCH
+        }
+        COUGH_HIP_CHECK(hipGetLastError());
+        if (d_tap && tap_layer == int(i)) {
+            const long long total = (long long)n * s.c * s.h * s.w;
+            hipLaunchKernelGGL(cnn_nhwc_to_nchw_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dst,
+                               d_tap, s.c, s.h * s.w, total);
+            COUGH_HIP_CHECK(hipGetLastError());
+        }
+        cur = dst;
+        ch = s.h;
+        cw = s.w;
+    }
+    if (d_logits) {
+        hipLaunchKernelGGL(cnn_tail_kernel<T>, dim3(n), dim3(256), 0, st, cur, ch * cw, m->feat_c, m->hidden, m->d_w1,
+                           m->d_b1, m->d_w2, m->d_b2, d_logits, d_probs, d_preds);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    return COUGH_OK;
+}
+
+}  // namespace
+}  // namespace cough
+
+extern "C" void cough_cnn_destroy(cough_cnn* m) {
+    if (!m) return;
+    for (auto& l : m->layers) {
+        (void)hipFree(l.d_w);
+        (void)hipFree(l.d_b);
+    }
+    (void)hipFree(m->d_w1);
+    (void)hipFree(m->d_b1);
+    (void)hipFree(m->d_w2);
+    (void)hipFree(m->d_b2);
+    delete m;
+}
+
+extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int dtype) {
+    using namespace cough;
+    COUGH_REQUIRE(out && w && w->blocks && w->fc1_w && w->fc1_b && w->fc2_w && w->fc2_b, COUGH_EINVAL,
+                  "cough_cnn_create: NULL argument");
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16, COUGH_EINVAL, "cough_cnn_create: unknown dtype %d", dtype);
+    COUGH_REQUIRE(w->n_blocks >= 2 && w->n_blocks <= 16, COUGH_EUNSUPPORTED, "cough_cnn_create: %d blocks (need 2..16)", w->n_blocks);
+    COUGH_REQUIRE(w->hidden >= 1 && w->hidden <= 256, COUGH_EUNSUPPORTED, "cough_cnn_create: hidden = %d (need 1..256)", w->hidden);
+    const int chunk = dtype == COUGH_DTYPE_BF16 ? 16 : 8;
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const cough_cnn_block& bk = w->blocks[i];
+        const cough_conv_bn& p = bk.conv;
+        COUGH_REQUIRE(p.w && p.b && p.bn_w && p.bn_b && p.bn_mean && p.bn_var, COUGH_EINVAL,
+                      "cough_cnn_create: NULL weight pointer in block %d", i);
+        COUGH_REQUIRE(bk.pool == 1 || bk.pool == 2, COUGH_EUNSUPPORTED, "cough_cnn_create: block %d pool = %d", i, bk.pool);
+        const bool sep = bk.dw_w != nullptr;
+        COUGH_REQUIRE(sep ? (bk.ksize == 1 && bk.dw_b) : bk.ksize == 3, COUGH_EUNSUPPORTED,
+                      "cough_cnn_create: block %d: need a 3x3 conv, or a depthwise 3x3 followed by a 1x1", i);
+        if (i == 0) {
+            COUGH_REQUIRE(bk.cin == 1 && !sep && bk.cout >= 8 && bk.cout <= 64 && bk.cout % chunk == 0, COUGH_EUNSUPPORTED,
+                          "cough_cnn_create: the first block must be a dense 3x3 conv of 1 input channel to 16..64 outputs");
+        } else {
+            COUGH_REQUIRE(bk.cin == w->blocks[i - 1].cout, COUGH_EINVAL, "cough_cnn_create: block %d cin != previous cout", i);
+            COUGH_REQUIRE(bk.cin % chunk == 0 && bk.cout % 32 == 0 && (bk.cout <= 128 || bk.cout % 128 == 0), COUGH_EUNSUPPORTED,
+                          "cough_cnn_create: block %d (%d -> %d channels): need cin %% %d == 0 and cout in {32, 64, 128k}", i,
+                          bk.cin, bk.cout, chunk);
+        }
+    }
+    COUGH_REQUIRE(w->blocks[w->n_blocks - 1].cout <= 256, COUGH_EUNSUPPORTED, "cough_cnn_create: last block > 256 channels");
+
+    cough_cnn* m = new cough_cnn();
+    m->dtype = dtype;
+    m->esize = dtype == COUGH_DTYPE_BF16 ? 2 : 4;
+    m->d_w1 = m->d_b1 = m->d_w2 = m->d_b2 = nullptr;
+    int err = COUGH_OK;
+    for (int i = 0; i < w->n_blocks && !err; ++i) {
+        const cough_cnn_block& bk = w->blocks[i];
+        const cough_conv_bn& p = bk.conv;
+        const int N = bk.cout, Cc = bk.cin, K = 9 * Cc;
+        std::vector<double> wd(size_t(N) * K), bd(N);   // dense 3x3, k = (kh*3 + kw)*C + c
+        for (int n = 0; n < N; ++n) {
+            double bacc = p.b[n];
+            for (int c = 0; c < Cc; ++c) {
+                if (bk.dw_w) {   // depthwise 3x3 then 1x1: one dense 3x3
+                    const double pw = p.w[size_t(n) * Cc + c];
+                    for (int t = 0; t < 9; ++t) wd[size_t(n) * K + t * Cc + c] = pw * double(bk.dw_w[size_t(c) * 9 + t]);
+                    bacc += pw * double(bk.dw_b[c]);
+                } else {
+                    for (int t = 0; t < 9; ++t) wd[size_t(n) * K + t * Cc + c] = p.w[(size_t(n) * Cc + c) * 9 + t];
+                }
+            }
+            const double scale = double(p.bn_w[n]) / std::sqrt(double(p.bn_var[n]) + double(w->bn_eps));
+            for (int k = 0; k < K; ++k) wd[size_t(n) * K + k] *= scale;
+            bd[n] = (bacc - double(p.bn_mean[n])) * scale + double(p.bn_b[n]);
+        }
+        cough_cnn::Layer l{Cc, N, 3, bk.pool, nullptr, nullptr};
+        std::vector<float> bf(N);
+        for (int n = 0; n < N; ++n) bf[n] = float(bd[n]);
+        if (i == 0) {
+            std::vector<float> wk(size_t(9) * N);
+            for (int n = 0; n < N; ++n)
+                for (int t = 0; t < 9; ++t) wk[size_t(t) * N + n] = float(wd[size_t(n) * 9 + t]);
+            err = cnn_upload(&l.d_w, wk);
+        } else if (m->esize == 4) {
+            std::vector<float> wf(wd.size());
+            for (size_t k = 0; k < wd.size(); ++k) wf[k] = float(wd[k]);
+            err = cnn_upload(&l.d_w, wf);
+        } else {
+            std::vector<bf16_t> wb(wd.size());
+            for (size_t k = 0; k < wd.size(); ++k) wb[k] = f2bf_host(float(wd[k]));
+            err = cnn_upload(&l.d_w, wb);
+        }
+        if (!err) err = cnn_upload(reinterpret_cast<void**>(&l.d_b), bf);
+        m->layers.push_back(l);
+    }
+    m->feat_c = w->blocks[w->n_blocks - 1].cout;
+    m->hidden = w->hidden;
+    if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_w1), std::vector<float>(w->fc1_w, w->fc1_w + size_t(m->hidden) * m->feat_c));
+    if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_b1), std::vector<float>(w->fc1_b, w->fc1_b + m->hidden));
+    if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_w2), std::vector<float>(w->fc2_w, w->fc2_w + size_t(2) * m->hidden));
+    if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_b2), std::vector<float>(w->fc2_b, w->fc2_b + 2));
+    if (err) {
+        cough_cnn_destroy(m);
+        return err;
+    }
+    *out = m;
+    return COUGH_OK;
+}
+
+extern "C" size_t cough_cnn_workspace_bytes(const cough_cnn* m, int n_clips, int height, int width) {
+    using namespace cough;
+    std::vector<CnnShape> shp;
+    if (!m || n_clips < 0 || height < 1 || width < 1 || !cnn_shapes(m, height, width, shp)) return 0;
+    size_t buf = 0;
+    for (const auto& s : shp) buf = std::max(buf, align256(size_t(n_clips) * s.h * s.w * s.c * m->esize));
+    return 2 * buf;
+}
+
+namespace {
+int cnn_run(const cough_cnn* m, const float* d_feat, int n_clips, int height, int width, float* d_logits, float* d_probs,
+            int* d_preds, void* d_workspace, size_t workspace_bytes, void* stream, int tap_layer, float* d_tap) {
+    using namespace cough;
+    COUGH_REQUIRE(m && d_feat && d_workspace, COUGH_EINVAL, "cough_cnn_forward: NULL argument");
+    COUGH_REQUIRE(n_clips >= 0 && height >= 1 && width >= 1, COUGH_EINVAL, "cough_cnn_forward: bad shape");
+    std::vector<CnnShape> shp;
+    COUGH_REQUIRE(cnn_shapes(m, height, width, shp), COUGH_EINVAL, "cough_cnn_forward: input %dx%d too small for the network",
+                  height, width);
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL, "cough_cnn_forward: workspace must be 256-byte aligned");
+    COUGH_REQUIRE(workspace_bytes >= cough_cnn_workspace_bytes(m, n_clips, height, width), COUGH_EWORKSPACE,
+                  "cough_cnn_forward: workspace too small");
+    if (n_clips == 0) return COUGH_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(d_workspace);
+    if (m->esize == 4)
+        return cnn_forward_impl<float>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap);
+    return cnn_forward_impl<bf16_t>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap);
+}
+}  // namespace
+
+extern "C" int cough_cnn_forward(const cough_cnn* m, const float* d_feat, int n_clips, int height, int width,
+                                 float* d_logits, float* d_probs, int* d_preds, void* d_workspace,
+                                 size_t workspace_bytes, void* stream) {
+    COUGH_REQUIRE(d_logits, COUGH_EINVAL, "cough_cnn_forward: NULL argument");
+    return cnn_run(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, d_workspace, workspace_bytes, stream, -1, nullptr);
+}
+
+extern "C" int cough_cnn_conv_output(const cough_cnn* m, const float* d_feat, int n_clips, int height, int width,
+                                     float* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    COUGH_REQUIRE(m && d_out, COUGH_EINVAL, "cough_cnn_conv_output: NULL argument");
+    return cnn_run(m, d_feat, n_clips, height, width, nullptr, nullptr, nullptr, d_workspace, workspace_bytes, stream,
+                   int(m->layers.size()) - 1, d_out);
+}

@@ -1,0 +1,37 @@
+// Element types and small helpers shared by the classifier translation units (resnet.hip, cnn.hip).
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+namespace cough {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef uint16_t bf16_t;   // storage type of bf16 activations / weights
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+inline bf16_t f2bf_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return bf16_t(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+
+}  // namespace
+}  // namespace cough

@@ -1,7 +1,9 @@
-"""Host-side mirror of the reference classifier interface, backed by the HIP kernels K2-K5.
+"""Host-side mirror of the reference classifier interface, backed by the HIP kernels K2-K5 (residual net) and
+``csrc/cnn.hip`` (the two conv-stack nets).
 
 Same names and constructor arguments as ``/root/reference/src/model.py``
-(``CoughDetectorResidual`` :210-265, ``ResidualBlock`` :268-293, ``create_model`` :296-316,
+(``ConvBlock`` :11-40, ``CoughDetector`` :43-141, ``CoughDetectorSmall`` :144-207,
+``CoughDetectorResidual`` :210-265, ``ResidualBlock`` :268-293, ``create_model`` :296-316,
 ``count_parameters`` :319-321).  The modules below are *parameter containers* with the reference's
 exact sub-module layout, so ``state_dict()`` / ``load_state_dict()`` use the reference's keys
 (``conv1.0.weight`` ... ``fc.2.bias``); ``forward`` does not run them -- it hands the tensors to
@@ -183,15 +185,207 @@ class CoughDetectorResidual(nn.Module):
         return out
 
 
+class ConvBlock(nn.Module):
+    """Parameter layout of the reference block (``src/model.py:11-40``): conv / bn (+ MaxPool2d, Dropout2d)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, padding: int = 1,
+                 pool_size: int = 2):
+        super().__init__()
+        if (kernel_size, stride, padding) != (3, 1, 1) or pool_size not in (1, 2):
+            raise ValueError("ConvBlock: the MI355X path implements kernel_size=3, stride=1, padding=1, pool_size 1 or 2")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.pool = nn.MaxPool2d(pool_size) if pool_size > 1 else nn.Identity()
+        self.dropout = nn.Dropout2d(0.1)
+
+    def forward(self, x):
+        raise RuntimeError("ConvBlock is executed inside CoughDetector.forward on the MI355X path")
+
+
+class _ConvStackNet(nn.Module):
+    """Shared host side of the two conv-stack classifiers: owns the ``cough_cnn`` handle and the workspace;
+    subclasses describe their blocks (``_describe``) in terms of their own state_dict keys."""
+
+    def _init_native(self, compute_dtype: str):
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_key = None
+        self._tensors = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.eval()
+
+    def _weights_key(self):
+        if self._tensors is None:
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self._tensors)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._tensors = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _release(self):
+        h = self.__dict__.get("_handle")
+        self.__dict__["_handle"] = None
+        if h is not None:
+            try:
+                _lib.load().cough_cnn_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _describe(self, sd: Dict[str, torch.Tensor]):
+        """-> (blocks, fc1 prefix, fc2 prefix, bn eps); a block is (conv prefix, bn prefix, depthwise prefix | None,
+        pool)."""
+        raise NotImplementedError
+
+    def _native(self) -> C.c_void_p:
+        key = self._weights_key()
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._release()
+        lib = _lib.load()
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+        blocks, fc1, fc2, eps = self._describe(sd)
+        arr = (_lib.CnnBlock * len(blocks))()
+        for i, (conv, bn, dw, pool) in enumerate(blocks):
+            w = sd[conv + ".weight"]
+            arr[i].cin, arr[i].cout, arr[i].ksize, arr[i].pool = int(w.shape[1]), int(w.shape[0]), int(w.shape[2]), pool
+            if dw is not None:
+                arr[i].cin = int(sd[dw + ".weight"].shape[0])
+                arr[i].dw_w, arr[i].dw_b = _lib.fptr(sd[dw + ".weight"]), _lib.fptr(sd[dw + ".bias"])
+            arr[i].conv = _lib.ConvBN(_lib.fptr(w), _lib.fptr(sd[conv + ".bias"]), _lib.fptr(sd[bn + ".weight"]),
+                                      _lib.fptr(sd[bn + ".bias"]), _lib.fptr(sd[bn + ".running_mean"]),
+                                      _lib.fptr(sd[bn + ".running_var"]))
+        cw = _lib.CnnWeights(len(blocks), arr, int(sd[fc1 + ".weight"].shape[0]), _lib.fptr(sd[fc1 + ".weight"]),
+                             _lib.fptr(sd[fc1 + ".bias"]), _lib.fptr(sd[fc2 + ".weight"]), _lib.fptr(sd[fc2 + ".bias"]),
+                             float(eps))
+        h = C.c_void_p()
+        _lib.check(lib.cough_cnn_create(C.byref(h), C.byref(cw), _lib.DTYPES[self.compute_dtype]), "cough_cnn_create")
+        self._handle, self._handle_key = h, key
+        return h
+
+    def _prepare(self, x: torch.Tensor):
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__} on the MI355X path is inference-only: call .eval()")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected input (B, 1, F, T), got {tuple(x.shape)}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        b, _, hgt, wid = xf.shape
+        lib, h = _lib.load(), self._native()
+        need = lib.cough_cnn_workspace_bytes(h, b, hgt, wid) if b else 0
+        if b and need == 0:
+            raise ValueError(f"input {hgt}x{wid} is too small for the network")
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        return lib, h, xf, dev
+
+    def _run(self, x: torch.Tensor, want_probs: bool):
+        src_dev = x.device
+        lib, h, xf, dev = self._prepare(x)
+        b, _, hgt, wid = xf.shape
+        logits = torch.empty((b, 2), dtype=torch.float32, device=dev)
+        probs = torch.empty((b, 2), dtype=torch.float32, device=dev) if want_probs else None
+        preds = torch.empty((b,), dtype=torch.int32, device=dev) if want_probs else None
+        if b:
+            _lib.check(lib.cough_cnn_forward(h, xf.data_ptr(), b, hgt, wid, logits.data_ptr(),
+                                             probs.data_ptr() if want_probs else None,
+                                             preds.data_ptr() if want_probs else None, self._workspace.data_ptr(),
+                                             self._workspace.numel(), torch.cuda.current_stream(dev).cuda_stream),
+                       "cough_cnn_forward")
+        if want_probs:
+            return logits.to(src_dev), probs.to(src_dev), preds.to(src_dev)
+        return logits.to(src_dev)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, want_probs=False)
+
+    def predict(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _, probs, preds = self._run(x, want_probs=True)
+        return preds.to(torch.int64), probs
+
+    def conv_output(self, x: torch.Tensor) -> torch.Tensor:
+        """Parity tap: output of the conv stack before the global mean, (B, C, h, w) float32."""
+        lib, h, xf, dev = self._prepare(x)
+        b, _, hgt, wid = xf.shape
+        oh, ow = hgt, wid
+        for _ in range(self._n_pools):
+            oh, ow = oh // 2, ow // 2
+        out = torch.empty((b, self._out_channels, oh, ow), dtype=torch.float32, device=dev)
+        if b:
+            _lib.check(lib.cough_cnn_conv_output(h, xf.data_ptr(), b, hgt, wid, out.data_ptr(), self._workspace.data_ptr(),
+                                                 self._workspace.numel(), torch.cuda.current_stream(dev).cuda_stream),
+                       "cough_cnn_conv_output")
+        return out
+
+
+class CoughDetector(_ConvStackNet):
+    """The reference's "standard" CNN (``src/model.py:43-141``): ConvBlock x len(channels) -> global mean ->
+    Linear -> ReLU -> Linear; (B, 1, F, T) float32 -> (B, 2) logits on hand-written gfx950 kernels."""
+
+    def __init__(self, n_mels: int = 64, num_classes: int = 2, in_channels: int = 1,
+                 channels: Tuple[int, ...] = (32, 64, 128, 256), fc_hidden: int = 128, dropout: float = 0.5,
+                 compute_dtype: str = "fp32"):
+        super().__init__()
+        if num_classes != 2 or in_channels != 1:
+            raise ValueError("CoughDetector: the MI355X path implements num_classes=2, in_channels=1")
+        self.n_mels, self.num_classes = n_mels, num_classes
+        layers, cur = [], in_channels
+        for out_ch in channels:
+            layers.append(ConvBlock(cur, out_ch))
+            cur = out_ch
+        self.conv_layers = nn.Sequential(*layers)
+        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Sequential(nn.Linear(channels[-1], fc_hidden), nn.ReLU(), nn.Dropout(dropout),
+                                nn.Linear(fc_hidden, num_classes))
+        self._n_pools, self._out_channels = len(channels), channels[-1]
+        self._init_native(compute_dtype)
+
+    def _describe(self, sd):
+        blocks = [(f"conv_layers.{i}.conv", f"conv_layers.{i}.bn", None, 2) for i in range(len(self.conv_layers))]
+        return blocks, "fc.0", "fc.3", self.conv_layers[0].bn.eps
+
+
+class CoughDetectorSmall(_ConvStackNet):
+    """The reference's lightweight CNN (``src/model.py:144-207``): conv3x3 + three depthwise-separable blocks ->
+    global mean -> Linear(128, 64) -> ReLU -> Linear(64, 2)."""
+
+    def __init__(self, n_mels: int = 64, num_classes: int = 2, in_channels: int = 1, compute_dtype: str = "fp32"):
+        super().__init__()
+        if num_classes != 2 or in_channels != 1:
+            raise ValueError("CoughDetectorSmall: the MI355X path implements num_classes=2, in_channels=1")
+        self.features = nn.Sequential(
+            nn.Conv2d(in_channels, 16, 3, padding=1), nn.BatchNorm2d(16), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(16, 16, 3, padding=1, groups=16), nn.Conv2d(16, 32, 1), nn.BatchNorm2d(32), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(32, 32, 3, padding=1, groups=32), nn.Conv2d(32, 64, 1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(64, 64, 3, padding=1, groups=64), nn.Conv2d(64, 128, 1), nn.BatchNorm2d(128), nn.ReLU(),
+            nn.AdaptiveAvgPool2d((1, 1)))
+        self.classifier = nn.Sequential(nn.Flatten(), nn.Linear(128, 64), nn.ReLU(), nn.Dropout(0.3),
+                                        nn.Linear(64, num_classes))
+        self._n_pools, self._out_channels = 3, 128
+        self._init_native(compute_dtype)
+
+    def _describe(self, sd):
+        blocks = [("features.0", "features.1", None, 2), ("features.5", "features.6", "features.4", 2),
+                  ("features.10", "features.11", "features.9", 2), ("features.15", "features.16", "features.14", 1)]
+        return blocks, "classifier.1", "classifier.4", self.features[1].eps
+
+
 def create_model(model_type: str = "standard", **kwargs) -> nn.Module:
-    """Factory with the reference's signature; only the model the shipped pipeline trains
-    (``train_with_data.py:50``: "residual") exists on the MI355X path."""
-    known = ["standard", "small", "residual"]
-    if model_type not in known:
-        raise ValueError(f"Unknown model type: {model_type}. Choose from {known}")
-    if model_type != "residual":
-        raise ValueError(f"model type {model_type!r} is not implemented on the MI355X path; use 'residual'")
-    return CoughDetectorResidual(**kwargs)
+    """Factory with the reference's signature (``src/model.py:296-316``)."""
+    models = {"standard": CoughDetector, "small": CoughDetectorSmall, "residual": CoughDetectorResidual}
+    if model_type not in models:
+        raise ValueError(f"Unknown model type: {model_type}. Choose from {list(models.keys())}")
+    return models[model_type](**kwargs)
 
 
 def count_parameters(model: nn.Module) -> int:

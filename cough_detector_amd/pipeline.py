@@ -17,7 +17,7 @@ from .preprocessing import AudioPreprocessor, _cuda_device
 
 
 class CoughPipeline:
-    def __init__(self, preprocessor: AudioPreprocessor, model: CoughDetectorResidual):
+    def __init__(self, preprocessor: AudioPreprocessor, model: torch.nn.Module):
         self.pre, self.model = preprocessor, model
         self._ws: Optional[torch.Tensor] = None
 
@@ -38,6 +38,21 @@ class CoughPipeline:
         preds = torch.empty((b,), dtype=torch.int32, device=dev) if want_probs else None
         feats = (torch.empty((b, self.pre.get_num_features(), self.pre.get_expected_time_frames()),
                              dtype=torch.float32, device=dev) if return_features else None)
+        if b and not isinstance(self.model, CoughDetectorResidual):
+            # conv-stack classifiers (CoughDetector / CoughDetectorSmall): featurise, then cough_cnn_forward
+            if feats is None:
+                feats = torch.empty((b, self.pre.get_num_features(), self.pre.get_expected_time_frames()),
+                                    dtype=torch.float32, device=dev)
+            if events:
+                events[0].record()
+            self.pre.featurize_batch(w, normalize=normalize, out=feats)
+            if events:
+                events[1].record()
+            if want_probs:
+                logits, probs, preds = self.model._run(feats[:, None], True)
+            else:
+                logits = self.model._run(feats[:, None], False)
+            return logits, probs, preds, (feats if return_features else None)
         if b:
             lib, fh, mh = _lib.load(), self.pre._native(), self.model._native()
             need = lib.cough_pipeline_workspace_bytes(fh, mh, b)

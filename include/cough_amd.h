@@ -154,6 +154,47 @@ int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips
 int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips,
                                  int height, int width, int which, float* d_out, void* stream);
 
+/* ------------------------------------------------------------------ conv-block classifiers
+ * Replaces CoughDetector.forward / predict (/root/reference/src/model.py:43-141, ConvBlock :11-40) and
+ * CoughDetectorSmall.forward / predict (:144-207) in eval mode.  Both are a stack of blocks
+ *     y = MaxPool2d(pool)( ReLU( BN( conv(x) ) ) )
+ * where conv is a dense 3x3 (padding 1), or -- dw_w != NULL -- a depthwise 3x3 (padding 1, groups = cin)
+ * followed by the 1x1 convolution `conv` (nothing in between), then a global mean, Linear(hidden), ReLU,
+ * Linear(2).  Pointers are HOST float32 tensors exactly as stored in the reference state_dict. */
+typedef struct cough_cnn_block {
+    int cin, cout;
+    int ksize;             /* of `conv`: 3, or 1 when dw_w is given */
+    const float* dw_w;     /* depthwise weight [cin][1][3][3] or NULL */
+    const float* dw_b;     /* depthwise bias   [cin] or NULL */
+    cough_conv_bn conv;    /* conv weight [cout][cin][ksize][ksize], bias, BatchNorm (running stats) */
+    int pool;              /* 2: MaxPool2d(2) after the ReLU; 1: none */
+} cough_cnn_block;
+
+typedef struct cough_cnn_weights {
+    int n_blocks;
+    const cough_cnn_block* blocks;   /* blocks[0].cin == 1 (the feature image) */
+    int hidden;
+    const float* fc1_w;    /* [hidden][blocks[n-1].cout] */
+    const float* fc1_b;
+    const float* fc2_w;    /* [2][hidden] */
+    const float* fc2_b;
+    float bn_eps;
+} cough_cnn_weights;
+
+typedef struct cough_cnn cough_cnn;
+
+int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int dtype /* COUGH_DTYPE_* */);
+void cough_cnn_destroy(cough_cnn* m);
+size_t cough_cnn_workspace_bytes(const cough_cnn* m, int n_clips, int height, int width);
+/* d_feat: [n_clips][1][height][width] float32 -> d_logits [n_clips][2]; d_probs / d_preds optional as above */
+int cough_cnn_forward(const cough_cnn* m, const float* d_feat, int n_clips, int height, int width,
+                      float* d_logits, float* d_probs, int* d_preds, void* d_workspace, size_t workspace_bytes,
+                      void* stream);
+/* Parity tap: runs the conv stack only and writes its output (before the global mean) to d_out as
+ * [n_clips][C][h][w] float32. */
+int cough_cnn_conv_output(const cough_cnn* m, const float* d_feat, int n_clips, int height, int width,
+                          float* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ fused pipeline (K1 -> K5)
  * waveform -> logits in one call: what CoughDetectorInference.process_audio_chunk does per window with
  * preprocessor.add_audio (/root/reference/src/inference.py:214) followed by predict (:217, :165-189), for a

@@ -45,3 +45,18 @@ def features_golden():
     import numpy as np
     g = np.load(os.path.join(GOLDEN, "features_golden.npz"))
     return {k: g[k] for k in g.files}
+
+
+@pytest.fixture(scope="session")
+def cnn_golden():
+    """{"x": tensor, "standard": (state_dict, vectors), "small": (state_dict, vectors)} from the reference modules."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+    out = {"x": torch.from_numpy(g["x"])}
+    for kind in ("standard", "small"):
+        sd = {k[len(kind) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(kind + ".sd.")}
+        vec = {k[len(kind) + 1:]: torch.from_numpy(g[k]) for k in g.files
+               if k.startswith(kind + ".") and not k.startswith(kind + ".sd.")}
+        out[kind] = (sd, vec)
+    return out

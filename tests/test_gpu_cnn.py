@@ -1,0 +1,86 @@
+"""CoughDetector ("standard") and CoughDetectorSmall on the HIP path (csrc/cnn.hip, through the C-ABI) against goldens
+produced by the REFERENCE modules (oracle/make_golden_cnn.py) and against the CPU oracle on fresh inputs."""
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from oracle import cnn as ocnn
+from parity import LOGIT_TOL, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["standard", "small"]
+
+
+def _model(kind, sd, dtype):
+    m = cda.create_model(kind, n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fp32_matches_reference_goldens(cnn_golden, kind):
+    sd, vec = cnn_golden[kind]
+    m = _model(kind, sd, "fp32")
+    x = cnn_golden["x"].cuda()
+    conv = m.conv_output(x).cpu()
+    assert conv.shape == vec["conv_out"].shape
+    cerr = float((conv - vec["conv_out"]).abs().max())
+    logits = m(x).cpu()
+    lerr = float((logits - vec["logits"]).abs().max())
+    preds, probs = m.predict(x)
+    print(f"{kind} fp32: conv_out {cerr:.2e}, logits {lerr:.2e}")
+    assert cerr < 1e-4 and lerr < 1e-4
+    assert torch.equal(preds.cpu(), vec["preds"]) and preds.dtype == torch.int64
+    assert float((probs.cpu() - vec["probs"]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_bf16_within_logit_tolerance(cnn_golden, kind):
+    """bf16 operands, f32 accumulate.  The goldens' Linear weights are scaled x8 twice (margins), which scales the
+    logit error the same way; the bound is LOGIT_TOL on the un-scaled network = 64 * LOGIT_TOL here."""
+    sd, vec = cnn_golden[kind]
+    m = _model(kind, sd, "bf16")
+    x = cnn_golden["x"].cuda()
+    logits = m(x).cpu()
+    lerr = float((logits - vec["logits"]).abs().max())
+    print(f"{kind} bf16: logits {lerr:.2e} (x64-scaled head)")
+    assert lerr < 64 * LOGIT_TOL
+    margin = (vec["logits"][:, 1] - vec["logits"][:, 0]).abs()
+    safe = margin > 2 * lerr
+    preds, _ = m.predict(x)
+    assert torch.equal(preds.cpu()[safe], vec["preds"][safe])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 64 * LOGIT_TOL)])
+def test_fresh_features_ragged_batch_and_other_sizes(cnn_golden, kind, dtype, tol):
+    """A batch that is not a multiple of any tile (37 clips), real featuriser output, and a second image size
+    (the networks are fully convolutional: global mean at the end)."""
+    sd, _ = cnn_golden[kind]
+    m = _model(kind, sd, dtype)
+    pre = cda.AudioPreprocessor(device="cuda", use_pcen=False, use_pre_emphasis=False, use_delta_delta=False,
+                                use_spectral_contrast=False)
+    feats = pre.featurize_batch(synth_batch(900, 37).cuda())[:, None]            # (37, 1, 90, 101)
+    ref = ocnn.FORWARD[kind](feats.cpu(), sd)
+    got = m(feats).cpu()
+    assert got.shape == (37, 2)
+    assert float((got - ref).abs().max()) < tol
+    small_img = feats[:5, :, :64, :47].contiguous()
+    assert float((m(small_img).cpu() - ocnn.FORWARD[kind](small_img.cpu(), sd)).abs().max()) < tol
+    assert m(feats[:0]).shape == (0, 2)
+    # batch invariance: per-clip results do not depend on the neighbours
+    assert torch.equal(m(feats[3:4]).cpu(), got[3:4])
+
+
+def test_interface_errors(cnn_golden):
+    sd, _ = cnn_golden["small"]
+    m = _model("small", sd, "fp32")
+    with pytest.raises(ValueError, match="expected input"):
+        m(torch.zeros(2, 90, 101))
+    with pytest.raises(ValueError, match="too small"):
+        m(torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m.train()(torch.zeros(1, 1, 90, 101))
+    with pytest.raises(ValueError, match="Unknown model type"):
+        cda.create_model("huge")

@@ -55,8 +55,28 @@ def test_engine_rejects_unsupported_checkpoints(tmp_path):
     with pytest.raises(ValueError, match="n_fft"):
         cda.CoughDetectorInference(path, verbose=False)
     torch.save({"model_state_dict": sd, "config": {**CONFIG, "model_type": "small"}}, path)
-    with pytest.raises(ValueError, match="not implemented"):
+    with pytest.raises(RuntimeError, match="Missing key|Unexpected key"):   # a residual state_dict is not a "small" one
         cda.CoughDetectorInference(path, verbose=False)
+
+
+@pytest.mark.parametrize("kind", ["standard", "small"])
+def test_engine_runs_the_other_model_types(tmp_path, cnn_golden, kind):
+    """model_type "standard" / "small" checkpoints (src/inference.py:145-151) go through the same engine."""
+    from oracle import cnn as ocnn, featurizer as ofeat
+    sd, _ = cnn_golden[kind]
+    path = str(tmp_path / "m.pt")
+    torch.save({"model_state_dict": sd, "config": {**CONFIG, "model_type": kind}}, path)
+    now = {"t": 0.0}
+    eng = cda.CoughDetectorInference(path, verbose=False, clock=lambda: now["t"], confidence_threshold=2.0)
+    stream = synth.make_stream(4, 3.0)
+    for i in range(0, len(stream), 1600):
+        now["t"] = (i + 1600) / 16000.0
+        assert eng.process_audio_chunk(stream[i:i + 1600]) is None           # threshold 2.0 never fires
+    win = ofeat.RealtimeWindowerOracle(window_duration=1.0, hop_duration=0.25)
+    feats = torch.cat(win.add_audio(torch.from_numpy(stream)[None]))         # (9, 90, 101)
+    _, probs = ocnn.predict(kind, feats[:, None], sd)
+    assert len(eng.window_probs) == feats.shape[0] == 9
+    assert np.abs(np.array(eng.window_probs) - probs[:, 1].numpy()).max() < 1e-3
 
 
 def test_ring_write_and_window_gather():

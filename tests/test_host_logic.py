@@ -123,11 +123,25 @@ def test_model_state_dict_contract(resnet_golden):
     assert cda.count_parameters(m) == 290370
     with pytest.raises(ValueError, match="Unknown model type"):
         cda.create_model("resnet50")
-    with pytest.raises(ValueError, match="not implemented"):
-        cda.create_model("small")
+    # the other two reference models: same factory, reference state_dict keys (goldens from the reference modules)
+    assert isinstance(cda.create_model("small"), cda.CoughDetectorSmall)
+    assert isinstance(cda.create_model(), cda.CoughDetector)                 # the factory default is "standard"
     m.train()
     with pytest.raises(RuntimeError, match="inference-only"):
         m(torch.zeros(1, 1, 90, 101))
+
+
+def test_conv_stack_models_take_the_reference_state_dicts(cnn_golden):
+    for kind, n_params in (("standard", 421954), ("small", 21122)):
+        sd, _ = cnn_golden[kind]
+        m = cda.create_model(kind, n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        assert set(m.state_dict().keys()) == set(sd.keys())
+        m.load_state_dict(sd)                                                # strict
+        assert cda.count_parameters(m) == n_params
+    with pytest.raises(ValueError, match="in_channels"):
+        cda.CoughDetector(in_channels=3)
+    with pytest.raises(ValueError, match="compute_dtype"):
+        cda.CoughDetectorSmall(compute_dtype="fp8")
 
 
 def test_num_features_from_config():
