@@ -11,8 +11,10 @@
 //
 //   first block (Cin = 1)  cnn_first_kernel: direct f32 conv out of the (H, W) feature image, bias, ReLU, 2x2 max,
 //                          NHWC store; weights are wave-uniform (scalar loads)
-//   other blocks           cnn_conv_kernel<T, NT, POOL>: implicit GEMM on v_mfma_f32_32x32x2_f32 (T = float) or
-//                          v_mfma_f32_32x32x16_bf16, NHWC activations.  With POOL the GEMM rows are ordered
+//   other blocks           bf16 with >= 32 input / 64 output channels: conv_gemm_bf16_kernel<NT, POOL> (conv_gemm.h,
+//                          LDS-staged 128 x N tiles); otherwise cnn_conv_kernel<T, NT, POOL>: implicit GEMM on
+//                          v_mfma_f32_32x32x2_f32 (T = float) or v_mfma_f32_32x32x16_bf16 with operands straight
+//                          from global / L2, NHWC activations.  With POOL the GEMM rows are ordered
 //                          (pool window, dy, dx), so the 2x2 max is a max over 4 accumulator registers of one lane
 //                          and the un-pooled conv output never exists (floor mode: the odd last row / column is
 //                          never computed)
@@ -23,6 +25,7 @@
 #include "common.h"
 #include "internal.h"
 #include "nn_common.h"
+#include "conv_gemm.h"
 
 namespace cough {
 namespace {
@@ -252,8 +255,10 @@ size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct cough_cnn {
     struct Layer {
         int cin, cout, ks, pool;
-        void* d_w;      // first layer: float [9][N]; others: T [N][ks*ks*cin]
+        void* d_w;      // first layer: float [9][N]; others: T [N][ktot]
         float* d_b;
+        int ktot;       // row pitch of d_w: ks*ks*cin, padded to a multiple of 64 for the LDS-staged bf16 GEMM
+        bool gemm;      // bf16, cin % 32 == 0, cout % 64 == 0: conv_gemm_bf16_kernel
     };
     int dtype;
     size_t esize;
@@ -309,6 +314,21 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
             else
                 hipLaunchKernelGGL((cnn_first_kernel<T, false>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
                                    static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
+        } else if (l.gemm) {
+            if constexpr (sizeof(T) == 2) {
+                ConvArgs<bf16_t> a{};
+                a.in = cur; a.H = ch; a.W = cw; a.C = l.cin; a.KH = a.KW = 3; a.stride = 1; a.pad = 1;
+                a.in2 = nullptr; a.H2 = a.W2 = 0; a.C2 = 0; a.stride2 = 1;
+                a.wp = static_cast<const bf16_t*>(l.d_w); a.bias = l.d_b;
+                a.out = dst; a.OH = s.h; a.OW = s.w; a.N = l.cout; a.Ktot = l.ktot;
+                a.M = (long long)n * s.h * s.w * (l.pool == 2 ? 4 : 1);
+                const int nt = l.cout % 128 == 0 ? 4 : 2;
+                const dim3 grid((unsigned)((a.M + CG_BM - 1) / CG_BM), (unsigned)(l.cout / (32 * nt)));
+                if (nt == 4 && l.pool == 2) hipLaunchKernelGGL((conv_gemm_bf16_kernel<4, true>), grid, dim3(256), 0, st, a);
+                else if (nt == 4) hipLaunchKernelGGL((conv_gemm_bf16_kernel<4, false>), grid, dim3(256), 0, st, a);
+                else if (l.pool == 2) hipLaunchKernelGGL((conv_gemm_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((conv_gemm_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
+            }
         } else {
             CnnConvArgs<T> a{};
             a.in = cur; a.H = ch; a.W = cw; a.C = l.cin; a.KS = l.ks;
@@ -416,7 +436,9 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
             for (int k = 0; k < K; ++k) wd[size_t(n) * K + k] *= scale;
             bd[n] = (bacc - double(p.bn_mean[n])) * scale + double(p.bn_b[n]);
         }
-        cough_cnn::Layer l{Cc, N, 3, bk.pool, nullptr, nullptr};
+        cough_cnn::Layer l{Cc, N, 3, bk.pool, nullptr, nullptr, K, false};
+        l.gemm = i > 0 && m->esize == 2 && Cc % 32 == 0 && N % 64 == 0;
+        if (l.gemm) l.ktot = ((K + 63) / 64) * 64;
         std::vector<float> bf(N);
         for (int n = 0; n < N; ++n) bf[n] = float(bd[n]);
         if (i == 0) {
@@ -429,8 +451,9 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
             for (size_t k = 0; k < wd.size(); ++k) wf[k] = float(wd[k]);
             err = cnn_upload(&l.d_w, wf);
         } else {
-            std::vector<bf16_t> wb(wd.size());
-            for (size_t k = 0; k < wd.size(); ++k) wb[k] = f2bf_host(float(wd[k]));
+            std::vector<bf16_t> wb(size_t(N) * l.ktot, 0);
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) wb[size_t(n) * l.ktot + k] = f2bf_host(float(wd[size_t(n) * K + k]));
             err = cnn_upload(&l.d_w, wb);
         }
         if (!err) err = cnn_upload(reinterpret_cast<void**>(&l.d_b), bf);

@@ -92,3 +92,48 @@ extern "C" int cough_window_gather(const float* d_rings, int ring_len, const int
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
+
+// ------------------------------------------------------------------------------------------ SpecAugment masks
+namespace cough {
+namespace {
+struct MaskSet {
+    int n;
+    int axis[COUGH_MAX_MASKS], start[COUGH_MAX_MASKS], end[COUGH_MAX_MASKS];
+};
+// one pass: out = masked ? 0 : in.  4 floats per thread where the row length allows aligned float4 access.
+__global__ __launch_bounds__(256) void mask_axes_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        long long total, int height, int width, MaskSet ms) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int col = int(idx % width);
+    const int row = int((idx / width) % height);
+    bool hit = false;
+    for (int k = 0; k < ms.n; ++k) {
+        const int i = ms.axis[k] == 0 ? row : col;
+        hit = hit || (i >= ms.start[k] && i < ms.end[k]);
+    }
+    out[idx] = hit ? 0.f : in[idx];
+}
+}  // namespace
+}  // namespace cough
+
+extern "C" int cough_mask_axes(const float* d_in, float* d_out, long long n_images, int height, int width, int n_masks,
+                               const int* axis, const int* start, const int* end, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_in && d_out && (n_masks == 0 || (axis && start && end)), COUGH_EINVAL, "cough_mask_axes: NULL argument");
+    COUGH_REQUIRE(n_images >= 0 && height >= 1 && width >= 1, COUGH_EINVAL, "cough_mask_axes: bad shape");
+    COUGH_REQUIRE(n_masks >= 0 && n_masks <= COUGH_MAX_MASKS, COUGH_EINVAL, "cough_mask_axes: n_masks = %d (0..%d)", n_masks,
+                  COUGH_MAX_MASKS);
+    MaskSet ms{};
+    ms.n = n_masks;
+    for (int k = 0; k < n_masks; ++k) {
+        COUGH_REQUIRE(axis[k] == 0 || axis[k] == 1, COUGH_EINVAL, "cough_mask_axes: axis[%d] = %d (0 = rows, 1 = columns)", k, axis[k]);
+        ms.axis[k] = axis[k]; ms.start[k] = start[k]; ms.end[k] = end[k];
+    }
+    const long long total = n_images * height * width;
+    if (total == 0) return COUGH_OK;
+    hipLaunchKernelGGL(mask_axes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_in, d_out, total, height, width, ms);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}

@@ -209,6 +209,15 @@ int cough_pipeline_forward(const cough_featurizer* f, const cough_resnet* m, con
                            float* d_probs, int* d_preds, void* d_workspace, size_t workspace_bytes, void* stream,
                            void* ev_featurize_begin, void* ev_featurize_end /* optional hipEvent_t, may be NULL */);
 
+/* ------------------------------------------------------------------ SpecAugment masking (training-side featurisation)
+ * Replaces the masked_fill of T.FrequencyMasking / T.TimeMasking as SpecAugment.__call__ applies them
+ * (/root/reference/src/augmentation.py:303-331): every image of the batch gets the same masks.  d_in / d_out:
+ * [n_images][height][width] float32 (d_out may equal d_in); mask k zeroes rows (axis 0, frequency) or columns
+ * (axis 1, time) start[k] <= i < end[k].  The caller draws the masks (host RNG, as the reference does). */
+#define COUGH_MAX_MASKS 16
+int cough_mask_axes(const float* d_in, float* d_out, long long n_images, int height, int width, int n_masks,
+                    const int* axis, const int* start, const int* end, void* stream);
+
 /* ------------------------------------------------------------------ resampler (front of process())
  * Replaces T.Resample(orig, 16000)(waveform) (/root/reference/src/preprocessing.py:146-183): polyphase
  * windowed-sinc FIR.  d_kernel: device [new][K] float32, K = 2*width + orig, built by the caller the way

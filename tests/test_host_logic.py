@@ -149,3 +149,19 @@ def test_num_features_from_config():
     shipped = dict(n_mels=64, n_mfcc=13, use_mfcc=True, use_delta_delta=False, use_spectral_contrast=False)
     assert num_features_from_config(shipped) == 90
     assert num_features_from_config({}) == 110             # the reference's fall-back defaults
+
+
+def test_spec_augment_draw_order_matches_oracle():
+    """Host half of SpecAugment (no GPU): the coin and the mask draws consume the RNGs exactly as the restatement."""
+    import random
+    from cough_detector_amd.augmentation import SpecAugment
+    from oracle import augmentation as oaug
+    aug = SpecAugment(freq_mask_param=10, time_mask_param=20, n_freq_masks=2, n_time_masks=2, p=1.0)
+    torch.manual_seed(11)
+    masks = aug.draw_masks(90, 101)
+    torch.manual_seed(11)
+    want = [(0,) + oaug.draw_mask(10, 90) for _ in range(2)] + [(1,) + oaug.draw_mask(20, 101) for _ in range(2)]
+    assert masks == want and all(e - s < (10 if a == 0 else 20) for a, s, e in masks)
+    x = torch.ones(1, 4, 4)
+    random.seed(0)
+    assert SpecAugment(p=0.0)(x) is x                       # the coin (python `random`) says no: input returned as is
