@@ -231,12 +231,11 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         dft16(z);   // z[k2] = Z[j + 16*k2]
 
         // partner Z[256-k] lives in lane (16-j)&15, register 15-k2 (j>=1) or 16-k2 (j==0)
-        const int src = (lane & 48) | ((16 - j) & 15);
-        float2 rv[8];
+        float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror (j -> 15 - j), then rotate right by one
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            rv[r].x = __shfl(z[8 + r].x, src, 64);
-            rv[r].y = __shfl(z[8 + r].y, src, 64);
+            rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
+            rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
         }
         wave_lds_fence();
 #pragma unroll
