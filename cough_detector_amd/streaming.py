@@ -12,7 +12,11 @@ every ``hop`` samples (``/root/reference/src/preprocessing.py:597-610``) and
   residual blocks, head);
 * the only host<->device traffic per tick is the chunk upload and one (n_windows,) probability download;
 * smoothing (deque mean), threshold, debounce and the "drop the rest of this chunk's windows after a
-  detection" rule are the reference's, per stream, on an injectable clock.
+  detection" rule are the reference's, per stream, on an injectable clock;
+* the steady state -- every stream pushed together with a fixed chunk length, at most one window per stream per
+  tick -- is launch-bound (five small kernels and three copies), so it is captured once into two HIP graphs
+  (chunk upload + ring write; the same + gather + pipeline + probability download) and replayed per tick: the
+  write positions / window starts travel through one pinned int64 buffer, nothing else changes between ticks.
 """
 from __future__ import annotations
 
@@ -33,7 +37,7 @@ class MultiStreamDetector:
     def __init__(self, model, n_streams: int, sample_rate: int = 16000, window_duration: float = 1.0,
                  hop_duration: float = 0.25, confidence_threshold: float = 0.5, smoothing_window: int = 3,
                  debounce_seconds: float = 0.5, clock: Optional[Callable[[], float]] = None,
-                 max_chunk: int = 16000, preprocessor: Optional[AudioPreprocessor] = None):
+                 max_chunk: int = 16000, preprocessor: Optional[AudioPreprocessor] = None, use_graphs: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
         self.dev = torch.device("cuda", torch.cuda.current_device())
@@ -56,6 +60,8 @@ class MultiStreamDetector:
         self.clock = clock or (lambda: __import__("time").time())
         self.window_probs: List[List[float]] = [[] for _ in range(n_streams)]
         self._lib = _lib.load()
+        self.use_graphs = use_graphs
+        self._g = None            # captured steady state: dict(length, buffers, graphs)
 
     def reset(self):
         self.written[:] = 0
@@ -63,6 +69,112 @@ class MultiStreamDetector:
         self.last_detection[:] = 0
         for h in self.history:
             h.clear()
+
+    # ------------------------------------------------------------------ captured steady state
+    def _capture(self, length: int):
+        """Two HIP graphs for "all streams, chunk of `length` samples": write only / write + one window per stream."""
+        n, dev = self.n_streams, self.dev
+        g = dict(length=length,
+                 h_chunks=torch.empty((n, length), dtype=torch.float32).pin_memory(),
+                 h_meta=torch.zeros(2 * n, dtype=torch.int64).pin_memory(),      # [write positions | window starts]
+                 h_probs=torch.empty((n, 2), dtype=torch.float32).pin_memory(),
+                 d_chunks=torch.empty((n, length), dtype=torch.float32, device=dev),
+                 d_meta=torch.zeros(2 * n, dtype=torch.int64, device=dev),
+                 d_ids=torch.arange(n, dtype=torch.int32, device=dev),
+                 windows=torch.zeros((n, self.window), dtype=torch.float32, device=dev))
+
+        def write():
+            st = torch.cuda.current_stream(dev).cuda_stream
+            g["d_chunks"].copy_(g["h_chunks"], non_blocking=True)
+            g["d_meta"].copy_(g["h_meta"], non_blocking=True)
+            _lib.check(self._lib.cough_ring_write(self.rings.data_ptr(), self.ring_len, g["d_chunks"].data_ptr(), length,
+                                                  g["d_ids"].data_ptr(), g["d_meta"].data_ptr(), n, st), "cough_ring_write")
+
+        def classify():
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(self._lib.cough_window_gather(self.rings.data_ptr(), self.ring_len, g["d_ids"].data_ptr(),
+                                                     g["d_meta"][n:].data_ptr(), n, self.window,
+                                                     g["windows"].data_ptr(), st), "cough_window_gather")
+            _, probs, _, _ = self.pipe._run(g["windows"], True, True, False)   # no int64 cast, no strided slice:
+            g["h_probs"].copy_(probs, non_blocking=True)                        # the graph holds kernels + 3 copies only
+
+        rings_before = self.rings.clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # warm-up outside capture: allocators, workspaces, lazy handles
+            for _ in range(2):
+                write()
+                classify()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g["write"], g["full"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["write"]):
+            write()
+        with torch.cuda.graph(g["full"]):
+            write()
+            classify()
+        self.rings.copy_(rings_before)             # the warm-up wrote h_chunks garbage at position 0
+        g["done"] = torch.cuda.Event()
+        g["done"].record()
+        torch.cuda.synchronize(dev)
+        return g
+
+    def _push_graph(self, chunks: torch.Tensor, length: int) -> Optional[np.ndarray]:
+        """Steady-state tick through the captured graphs.  Returns the (n_streams,) cough probabilities when a
+        window completed on every stream, an empty array when none did, None when the tick does not fit the
+        captured shape (the caller then takes the eager path)."""
+        n = self.n_streams
+        after = self.written + length
+        ready = after - self.next_start >= self.window
+        two = after - (self.next_start + self.hop) >= self.window            # a second window in the same tick
+        if ready.any() != ready.all() or two.any():
+            return None
+        if self._g is None or self._g["length"] != length:
+            try:
+                self._g = self._capture(length)
+            except Exception as exc:                                        # graphs unavailable: stay eager
+                import warnings
+                warnings.warn(f"MultiStreamDetector: HIP graph capture failed ({exc}); using eager launches")
+                self.use_graphs = False
+                return None
+        g = self._g
+        g["done"].synchronize()                    # the previous replay has consumed the pinned staging buffers
+        g["h_chunks"].copy_(chunks)
+        meta = g["h_meta"].numpy()
+        meta[:n] = self.written
+        meta[n:] = self.next_start
+        self.written += length
+        if not ready.all():
+            g["write"].replay()                                             # no host sync on ticks without windows
+            g["done"].record()
+            return np.empty(0, dtype=np.float32)
+        g["full"].replay()
+        g["done"].record()
+        self.next_start += self.hop
+        while not g["done"].query():                                        # the one host sync of the tick; polled:
+            pass                                                            # an interrupt-driven wait costs ~50 us
+        return g["h_probs"].numpy()[:, 1].copy()
+
+    def _decide(self, w_ids, p) -> List[Tuple[int, float, float]]:
+        """Smoothing / threshold / debounce per stream (src/inference.py:219-241) for the windows of one tick."""
+        detections = []
+        now = self.clock()
+        fired = set()
+        for k, s in enumerate(w_ids):
+            if s in fired:                               # inference.py:239: later windows of this chunk are dropped
+                continue
+            conf = float(p[k])
+            self.window_probs[s].append(conf)
+            h = self.history[s]
+            h.append(conf)
+            # np.mean of the reference (inference.py:223) adds < 8 float64 values left to right, as sum() does;
+            # calling it per stream costs ~5 us, i.e. more than the GPU work of a 64-stream tick
+            smoothed = sum(h) / len(h) if len(h) < 8 else float(np.mean(h))
+            if smoothed >= self.threshold and now - self.last_detection[s] >= self.debounce:
+                self.last_detection[s] = now
+                detections.append((int(s), now, smoothed))
+                fired.add(s)
+        return detections
 
     def push(self, chunks, stream_ids=None) -> List[Tuple[int, float, float]]:
         """chunks: (n, L) float32 (numpy or torch, host or device), one row per stream in ``stream_ids``
@@ -75,6 +187,10 @@ class MultiStreamDetector:
         ids = np.arange(self.n_streams, dtype=np.int32) if stream_ids is None else np.asarray(stream_ids, np.int32)
         if len(ids) != n or length > self.max_chunk:
             raise ValueError("push: one row per stream id, chunk length <= max_chunk")
+        if self.use_graphs and stream_ids is None and n == self.n_streams and not chunks.is_cuda and length <= self.hop:
+            p = self._push_graph(chunks, length)
+            if p is not None:
+                return self._decide(list(range(n)), p) if len(p) else []
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         d_chunks = chunks.to(self.dev, torch.float32, non_blocking=True).contiguous()
         meta = torch.from_numpy(np.concatenate([ids.astype(np.int64), self.written[ids]])).to(self.dev, non_blocking=True)
@@ -103,18 +219,4 @@ class MultiStreamDetector:
         _, probs = self.pipe.predict(windows, normalize=True)
         p = probs[:, 1].to("cpu").numpy()               # the one host sync of the tick
 
-        detections = []
-        now = self.clock()
-        fired = set()
-        for k, s in enumerate(w_ids):
-            if s in fired:                               # inference.py:239: later windows of this chunk are dropped
-                continue
-            conf = float(p[k])
-            self.window_probs[s].append(conf)
-            self.history[s].append(conf)
-            smoothed = float(np.mean(self.history[s]))
-            if smoothed >= self.threshold and now - self.last_detection[s] >= self.debounce:
-                self.last_detection[s] = now
-                detections.append((int(s), now, smoothed))
-                fired.add(s)
-        return detections
+        return self._decide(w_ids, p)

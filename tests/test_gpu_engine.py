@@ -140,3 +140,33 @@ def test_multi_stream_detector_matches_per_stream_oracles():
         assert len(refs[s].window_probs) > 5
         tail = det.window_probs[s][-len(refs[s].window_probs):]
         assert np.abs(np.array(tail) - np.array(refs[s].window_probs)).max() < 1e-3
+
+
+def test_graph_replay_equals_eager_launches():
+    """The captured steady state (two HIP graphs) must give the probabilities of the eager launch chain bit for bit,
+    including ticks that fall back to eager (a subset of streams, a longer chunk) in between."""
+    from cough_detector_amd.streaming import MultiStreamDetector
+    sd = synth.random_state_dict(seed=5)
+    S = 6
+    streams = np.stack([synth.make_stream(40 + s, 4.0) for s in range(S)])
+    runs = []
+    for use_graphs in (True, False):
+        model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        model.load_state_dict(sd)
+        now = {"t": 0.0}
+        det = MultiStreamDetector(model, S, confidence_threshold=0.5, clock=lambda: now["t"], use_graphs=use_graphs)
+        events = []
+        pos = 0
+        for k in range(30):
+            now["t"] = (pos + 1600) / 16000.0
+            if k == 17:                                   # one tick feeds only three of the streams (eager path) ...
+                events.append(det.push(streams[:3, pos:pos + 1600], stream_ids=[0, 1, 2]))
+                events.append(det.push(streams[3:, pos:pos + 1600], stream_ids=[3, 4, 5]))   # ... then the rest
+            else:
+                events.append(det.push(streams[:, pos:pos + 1600]))
+            pos += 1600
+        runs.append(([list(p) for p in det.window_probs], events, det._g is not None))
+    (pg, eg, used), (pe, ee, unused) = runs
+    assert used and not unused                            # the graph path really ran
+    assert all(len(p) == 9 for p in pg)
+    assert pg == pe and eg == ee
