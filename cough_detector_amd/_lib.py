@@ -28,7 +28,7 @@ SYMBOLS = (
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
-    "cough_mask_axes", "cough_resample", "cough_ring_write", "cough_window_gather",
+    "cough_mask_axes", "cough_prepare_clip", "cough_resample", "cough_ring_write", "cough_window_gather",
 )
 
 
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
         lib.cough_pipeline_workspace_bytes.restype = C.c_size_t
         lib.cough_pipeline_forward.argtypes = [vp, vp, vp, ll, i, i, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
         lib.cough_mask_axes.argtypes = [vp, vp, ll, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), vp]
+        lib.cough_prepare_clip.argtypes = [vp, ll, i, i, vp, i, i, vp]
         lib.cough_resample.argtypes = [vp, ll, i, i, vp, i, i, i, vp, ll, i, vp]
         lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
         lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]

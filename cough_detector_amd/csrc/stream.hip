@@ -137,3 +137,56 @@ extern "C" int cough_mask_axes(const float* d_in, float* d_out, long long n_imag
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
+
+// ------------------------------------------------------------------------------------------ clip preparation
+namespace cough {
+namespace {
+// one workgroup per clip (a file-level operation): pass 1 takes the peak of the mono signal, pass 2 writes the
+// centre-trimmed / zero-padded, normalised window
+__global__ __launch_bounds__(1024) void prepare_clip_kernel(const float* __restrict__ in, long long in_stride, int C, int n,
+                                                            float* __restrict__ out, int out_len, int normalize) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const float fc = float(C);
+    auto mono = [&](int i) {   // torch.mean(dim=0): channels summed in order, divided by the count
+        float s = in[i];
+        for (int c = 1; c < C; ++c) s += in[c * in_stride + i];
+        return C == 1 ? s : s / fc;
+    };
+    float peak = 0.f;
+    if (normalize) {
+        for (int i = tid; i < n; i += blockDim.x) peak = fmaxf(peak, fabsf(mono(i)));
+        peak = wave_max(peak);
+        if ((tid & 63) == 0) red[tid >> 6] = peak;
+        __syncthreads();
+        peak = red[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) peak = fmaxf(peak, red[w]);
+    }
+    const bool scale = normalize && peak > 0.f;   // all-zero input: unchanged (preprocessing.py:209-212)
+    // n > out_len: window [start, start + out_len), start = (n - out_len) / 2; n < out_len: left = (out_len - n) / 2
+    const int shift = n >= out_len ? (n - out_len) / 2 : -((out_len - n) / 2);
+    for (int o = tid; o < out_len; o += blockDim.x) {
+        const int i = o + shift;
+        float v = 0.f;
+        if (i >= 0 && i < n) {
+            v = mono(i);
+            if (scale) v = v / peak;
+        }
+        out[o] = v;
+    }
+}
+}  // namespace
+}  // namespace cough
+
+extern "C" int cough_prepare_clip(const float* d_in, long long in_stride, int n_channels, int n_samples, float* d_out,
+                                  int out_len, int flags, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_in && d_out, COUGH_EINVAL, "cough_prepare_clip: NULL argument");
+    COUGH_REQUIRE(n_channels >= 1 && n_samples >= 1 && out_len >= 1 && in_stride >= n_samples, COUGH_EINVAL,
+                  "cough_prepare_clip: bad shape (%d channels x %d samples, stride %lld, out %d)", n_channels, n_samples,
+                  in_stride, out_len);
+    hipLaunchKernelGGL(prepare_clip_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_in, in_stride,
+                       n_channels, n_samples, d_out, out_len, (flags & COUGH_PREP_NORMALIZE) ? 1 : 0);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}

@@ -284,15 +284,28 @@ class AudioPreprocessor:
             raise ValueError("extract_spectral_contrast: this preprocessor was built with use_spectral_contrast=False")
         return self.extract_features(waveform)[:, -(self.n_contrast_bands + 1):]
 
+    def prepare_clip(self, waveform: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """to_mono -> normalize -> pad_or_trim of ``process`` (src/preprocessing.py:505-512) in one kernel:
+        (C, n) on the GPU -> (1, segment_samples) on the GPU.  The peak is that of the whole mono signal, as in the
+        reference (normalisation comes before the trim)."""
+        dev = _cuda_device()
+        w = waveform.to(device=dev, dtype=torch.float32)
+        if w.dim() != 2 or w.shape[0] < 1 or w.shape[1] < 1:
+            raise ValueError(f"prepare_clip: expected (channels, samples), got {tuple(waveform.shape)}")
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        out = torch.empty((1, self.segment_samples), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().cough_prepare_clip(w.data_ptr(), w.stride(0) if w.shape[0] > 1 else w.shape[1], w.shape[0],
+                                                  w.shape[1], out.data_ptr(), self.segment_samples,
+                                                  1 if normalize else 0, torch.cuda.current_stream(dev).cuda_stream),
+                   "cough_prepare_clip")
+        return out
+
     def process(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
-        """resample -> mono -> normalize -> pad/trim -> features (normalize fused into the kernel:
-        peak-normalising before a centre trim / zero pad equals doing it on the host first only when
-        the peak lies inside the kept window, so the host normalises when the length changes)."""
-        waveform = self.to_mono(self.resample(waveform, orig_sr))
-        if waveform.shape[1] == self.segment_samples:
-            return self.featurize_batch(waveform, normalize=True).to(self._out_device(waveform))
-        waveform = self.pad_or_trim(self.normalize(waveform))
-        return self.extract_features(waveform)
+        """resample -> mono -> normalize -> pad/trim -> features, as src/preprocessing.py:491-517: ``cough_resample``,
+        ``cough_prepare_clip`` and the featurise kernel; nothing runs on the host or in torch ops."""
+        clip = self.prepare_clip(self.resample(waveform, orig_sr), normalize=True)
+        return self.featurize_batch(clip, normalize=False).to(self._out_device(waveform))
 
     def process_file(self, path: str) -> torch.Tensor:
         return self.process(*self.load_audio(path))

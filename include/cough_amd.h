@@ -228,6 +228,15 @@ int cough_resample(const float* d_in, long long in_stride, int n_rows, int in_le
                    int orig, int new_freq, int width, float* d_out, long long out_stride, int out_len,
                    void* stream);
 
+/* Middle of AudioPreprocessor.process (/root/reference/src/preprocessing.py:505-512): to_mono (:185-197, mean over
+ * channels), normalize (:199-212, divide by the peak of the WHOLE mono signal when it is > 0) and pad_or_trim
+ * (:358-385, centre trim / symmetric zero pad, the odd sample on the right) in one launch.
+ * d_in: [n_channels] rows of n_samples float32 at d_in + c*in_stride; d_out: out_len float32.
+ * flags: COUGH_PREP_NORMALIZE. */
+#define COUGH_PREP_NORMALIZE 1
+int cough_prepare_clip(const float* d_in, long long in_stride, int n_channels, int n_samples, float* d_out,
+                       int out_len, int flags, void* stream);
+
 /* ------------------------------------------------------------------ streaming windows (K6)
  * Device-side counterpart of RealtimePreprocessor.add_audio's FIFO
  * (/root/reference/src/preprocessing.py:582-616) for many concurrent streams: each stream owns

@@ -278,3 +278,18 @@ def test_mel_only_configuration():
     ref = ofeat.extract_features_batch(w, use_mfcc=False)
     assert got.shape == ref.shape == (8, 64, 101)
     assert float((got - ref).abs().max()) < FEAT_TOL
+
+
+@pytest.mark.parametrize("channels,n", [(1, 16000), (2, 20801), (3, 7999), (2, 16000), (1, 1), (2, 48000)])
+def test_prepare_clip_is_bit_exact(pre, channels, n):
+    """cough_prepare_clip = to_mono -> normalize -> pad_or_trim (preprocessing.py:185-212, :358-385): mean and
+    division are single IEEE operations, so the result equals the restatement bit for bit."""
+    g = torch.Generator().manual_seed(channels * 100003 + n)
+    w = (torch.rand((channels, n), generator=g) - 0.5) * 1.7
+    got = pre.prepare_clip(w.cuda()).cpu()
+    want = ofeat.pad_or_trim(ofeat.normalize(ofeat.to_mono(w)))
+    assert got.shape == want.shape == (1, 16000)
+    assert torch.equal(got, want)
+    raw = pre.prepare_clip(w.cuda(), normalize=False).cpu()
+    assert torch.equal(raw, ofeat.pad_or_trim(ofeat.to_mono(w)))
+    assert torch.equal(pre.prepare_clip(torch.zeros(channels, n).cuda()).cpu(), torch.zeros(1, 16000))   # no 0 / 0
