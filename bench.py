@@ -146,14 +146,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("COUGH_BENCH_FORCE_DIST") == "1":   # the env switch rehearses the path with one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL writes its version banner and warnings to stdout (at the first collective); stdout must carry exactly
+        # one JSON line, so library output is routed to stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)
 
     import cough_detector_amd as cda
     from cough_detector_amd import synth
-    from cough_detector_amd.distributed import gather_logits_round_robin
+    from cough_detector_amd.distributed import gather_logits_finish, gather_logits_start
 
     B, K, W = args.batch, args.steps, args.warmup
     # rank r owns global clips r, r+N, r+2N, ... (round-robin); synthetic, regenerated from the clip index
@@ -165,7 +170,7 @@ def main():
     feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
     pipe = cda.CoughPipeline(pre, model)
     fused = args.dtype == "bf16" and not args.featurize_only   # the stem runs inside the featurise kernel
-    gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if dist else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
 
@@ -185,12 +190,24 @@ def main():
         logits = pipe(wav, normalize=True, events=(ev[i][0], ev[i][1]) if timed else None)
         if timed:
             ev[i][2].record()
-        if world > 1:
-            return gather_logits_round_robin(logits, out=gathered)
+        if dist:
+            # publish the step's logits: the all-gather of step i runs on RCCL's stream while step i+1 computes;
+            # its un-interleave copy is issued one step later (every exchange is finished inside the timed region)
+            if pending:
+                gather_logits_finish(pending.pop(), out=gathered)
+            pending.append(gather_logits_start(logits))
+            return gathered
         return logits
+
+    pending = []
+
+    def drain():
+        while pending:
+            gather_logits_finish(pending.pop(), out=gathered)
 
     for i in range(W):
         step(i, False)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -198,6 +215,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         out = step(i, True)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -229,7 +247,7 @@ def main():
                                    if not args.featurize_only else
                                    "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32",
                        "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
-                       "collective": "all_gather(logits) per step" if world > 1 else "none",
+                       "collective": "all_gather(logits) per step, overlapped with the next step" if world > 1 else "none",
                        "weights": "random-init, BN stats randomised"},
             "roofline": {"kernel": "featurize_kernel<stem fused> (K1+K2)" if fused else "featurize_kernel (K1)",
                          "bound": "hbm", "achieved": round(achieved, 1),
@@ -248,7 +266,12 @@ def main():
             line["roofline_stft"] = stft_stage(pre, wav)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if dist:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        if dist:
+            os.dup2(2, 1)
     if dist:
         dist.destroy_process_group()
 

@@ -155,18 +155,32 @@ class AudioPreprocessor:
                                                   torch.cuda.current_stream(dev).cuda_stream), "cough_resample")
         return out
 
+    def _prepare(self, waveform: torch.Tensor, out_len: int, normalize: bool) -> torch.Tensor:
+        dev = _cuda_device()
+        w = waveform.to(device=dev, dtype=torch.float32)
+        if w.dim() != 2 or w.shape[0] < 1 or w.shape[1] < 1:
+            raise ValueError(f"expected (channels, samples), got {tuple(waveform.shape)}")
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        out = torch.empty((1, out_len), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().cough_prepare_clip(w.data_ptr(), w.stride(0) if w.shape[0] > 1 else w.shape[1], w.shape[0],
+                                                  w.shape[1], out.data_ptr(), out_len, 1 if normalize else 0,
+                                                  torch.cuda.current_stream(dev).cuda_stream), "cough_prepare_clip")
+        return out
+
     def to_mono(self, waveform: torch.Tensor) -> torch.Tensor:
+        """(C, n) -> (1, n): mean over channels (src/preprocessing.py:185-197), on the GPU; returned where the input lives."""
         if waveform.shape[0] == 1:
             return waveform
-        return waveform.mean(dim=0, keepdim=True)
+        return self._prepare(waveform, waveform.shape[1], False).to(waveform.device)
 
     def normalize(self, waveform: torch.Tensor) -> torch.Tensor:
-        """Peak-normalise (silent no-op on an all-zero input).  ``process`` / ``add_audio`` do NOT call
-        this: they set the fused-normalise flag of the kernel instead."""
-        max_val = waveform.abs().max()
-        if max_val > 0:
-            return waveform / max_val
-        return waveform
+        """Peak-normalise a (1, n) waveform (silent no-op on an all-zero input, src/preprocessing.py:199-212), on the
+        GPU.  ``add_audio`` and the pipeline do NOT call this: they set the fused-normalise flag of the featurise kernel."""
+        if waveform.dim() != 2 or waveform.shape[0] != 1:
+            max_val = waveform.abs().max()             # the reference also accepts other shapes: host plumbing
+            return waveform / max_val if max_val > 0 else waveform
+        return self._prepare(waveform, waveform.shape[1], True).to(waveform.device)
 
     def pad_or_trim(self, waveform: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:
         if length is None:
@@ -288,18 +302,7 @@ class AudioPreprocessor:
         """to_mono -> normalize -> pad_or_trim of ``process`` (src/preprocessing.py:505-512) in one kernel:
         (C, n) on the GPU -> (1, segment_samples) on the GPU.  The peak is that of the whole mono signal, as in the
         reference (normalisation comes before the trim)."""
-        dev = _cuda_device()
-        w = waveform.to(device=dev, dtype=torch.float32)
-        if w.dim() != 2 or w.shape[0] < 1 or w.shape[1] < 1:
-            raise ValueError(f"prepare_clip: expected (channels, samples), got {tuple(waveform.shape)}")
-        if w.stride(1) != 1:
-            w = w.contiguous()
-        out = torch.empty((1, self.segment_samples), dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().cough_prepare_clip(w.data_ptr(), w.stride(0) if w.shape[0] > 1 else w.shape[1], w.shape[0],
-                                                  w.shape[1], out.data_ptr(), self.segment_samples,
-                                                  1 if normalize else 0, torch.cuda.current_stream(dev).cuda_stream),
-                   "cough_prepare_clip")
-        return out
+        return self._prepare(waveform, self.segment_samples, normalize)
 
     def process(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
         """resample -> mono -> normalize -> pad/trim -> features, as src/preprocessing.py:491-517: ``cough_resample``,

@@ -30,6 +30,11 @@ def _worker(rank, world, port, n_total):
         assert torch.equal(full, want), (rank, full[:8])
         out = torch.empty(n_total, 2)
         assert cdist.gather_logits_round_robin(local, n_total=n_total, out=out) is out and torch.equal(out, want)
+        # two exchanges in flight, finished out of step with their launch (how bench.py overlaps them with compute)
+        h1 = cdist.gather_logits_start(local, n_total=n_total)
+        h2 = cdist.gather_logits_start(local * 2.0, n_total=n_total)
+        assert torch.equal(cdist.gather_logits_finish(h1), want)
+        assert torch.equal(cdist.gather_logits_finish(h2, out=out), want * 2.0)
     finally:
         dist.destroy_process_group()
 

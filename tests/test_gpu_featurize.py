@@ -293,3 +293,6 @@ def test_prepare_clip_is_bit_exact(pre, channels, n):
     raw = pre.prepare_clip(w.cuda(), normalize=False).cpu()
     assert torch.equal(raw, ofeat.pad_or_trim(ofeat.to_mono(w)))
     assert torch.equal(pre.prepare_clip(torch.zeros(channels, n).cuda()).cpu(), torch.zeros(1, 16000))   # no 0 / 0
+    mono = pre.to_mono(w)                                      # the reference's helper methods run the same kernel
+    assert not mono.is_cuda and torch.equal(mono, ofeat.to_mono(w))
+    assert torch.equal(pre.normalize(mono), ofeat.normalize(ofeat.to_mono(w)))

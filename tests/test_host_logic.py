@@ -73,7 +73,12 @@ def test_preprocessor_interface_and_errors():
     assert torch.equal(p.pad_or_trim(x, 4), ofeat.pad_or_trim(x, 4))
     assert torch.equal(p.pad_or_trim(x, 15), ofeat.pad_or_trim(x, 15))
     z = torch.zeros(1, 5)
-    assert p.normalize(z) is z
+    if torch.cuda.is_available():
+        assert torch.equal(p.normalize(z), z)               # all-zero input: unchanged, no 0 / 0 (:209-212)
+    else:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):   # normalize / to_mono are kernels too
+            p.normalize(z)
+    assert p.to_mono(z) is z                                 # one channel: returned as is (:194-195)
     assert isinstance(cda.create_preprocessor(realtime=True, **SHIPPED), cda.RealtimePreprocessor)
 
 
