@@ -388,15 +388,23 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 //     ahead.  Only two workgroup barriers exist: after staging and between the two convolutions.
 //   * MFMA operands are swapped (weights = A, activations = B): a lane owns one pixel and 4 consecutive
 //     channels per register quad, so h and the output are written with 8-byte stores.
-template <int CIN, int COUT, int G, int MW, int WAVES>
+// XH_T x XW_T: the block's input size when it is known at compile time (the shipped 90x101 feature image gives
+// 22x25 and 11x13); every pixel <-> (clip, row, column) division of the staging and geometry code is then a
+// multiply-shift by a constant instead of a ~15-instruction reciprocal division (they were a quarter of the
+// kernel's vector instructions).  0: sizes come from RbArgs.
+template <int CIN, int COUT, int G, int MW, int WAVES, int XH_T = 0, int XW_T = 0>
 __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
     using Cfg = RbCfg<CIN, COUT, G, MW, WAVES>;
+    constexpr bool FIX = XH_T > 0;
+    const int XH = FIX ? XH_T : a.XH, XW = FIX ? XW_T : a.XW;
+    const int OH = FIX ? (XH_T - 1) / 2 + 1 : a.OH, OW = FIX ? (XW_T - 1) / 2 + 1 : a.OW;
+    auto qdiv = [&](int x, int d, float inv) { return FIX ? x / d : fdiv(x, d, inv); };   // d is a constant when FIX
     constexpr int THREADS = Cfg::THREADS, NT = Cfg::NT, KS1 = Cfg::KS1, KS2 = Cfg::KS2, KS = KS1 + KS2;
     constexpr int CHI = CIN / 8, CHO = COUT / 8, K2M = 9 * COUT;
     constexpr int D = 16;  // weight prefetch depth (k-steps)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int XHb = a.XH + 2, XWb = a.XW + 2, OHb = a.OH + 2, OWb = a.OW + 2;
-    const int per = a.OH * a.OW, M = G * per;
+    const int XHb = XH + 2, XWb = XW + 2, OHb = OH + 2, OWb = OW + 2;
+    const int per = OH * OW, M = G * per;
     bf16_t* ximg = reinterpret_cast<bf16_t*>(smem);
     bf16_t* himg = ximg + size_t(G) * XHb * XWb * CIN;
 
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
     // the borders of both LDS images are zeroed while the data is in flight, then the pieces are scattered to
     // their swizzled interior cells ---------------------------------------------------------------------
     {
-        const int npix = a.XH * a.XW, total = G * npix * CHI;
+        const int npix = XH * XW, total = G * npix * CHI;
         const int valid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * npix * CHI;   // pieces of real clips
         const uint4* src = reinterpret_cast<const uint4*>(a.x + (long long)clip0 * npix * CIN);
         constexpr int UN = 16;   // covers G*XH*XW*CIN/8 <= 16*THREADS pieces (host-checked)
@@ -435,11 +443,11 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
             v[u] = make_uint4(0, 0, 0, 0);
             if (i < valid) v[u] = src[i];
         }
-        const int nb_x = 2 * XWb + 2 * a.XH, nb_h = 2 * OWb + 2 * a.OH;
+        const int nb_x = 2 * XWb + 2 * XH, nb_h = 2 * OWb + 2 * OH;
         const float inv_x = 1.0f / float(nb_x), inv_h = 1.0f / float(nb_h);
         for (int i = tid; i < G * nb_x * CHI; i += THREADS) {
             const int j = i & (CHI - 1), bi = i / CHI;
-            const int g = fdiv(bi, nb_x, inv_x), bp = bi - g * nb_x;
+            const int g = qdiv(bi, nb_x, inv_x), bp = bi - g * nb_x;
             int row, col;
             if (bp < XWb) { row = 0; col = bp; }
             else if (bp < 2 * XWb) { row = XHb - 1; col = bp - XWb; }
@@ -448,21 +456,21 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
         }
         for (int i = tid; i < G * nb_h * CHO; i += THREADS) {
             const int j = i & (CHO - 1), bi = i / CHO;
-            const int g = fdiv(bi, nb_h, inv_h), bp = bi - g * nb_h;
+            const int g = qdiv(bi, nb_h, inv_h), bp = bi - g * nb_h;
             int row, col;
             if (bp < OWb) { row = 0; col = bp; }
             else if (bp < 2 * OWb) { row = OHb - 1; col = bp - OWb; }
             else { const int qq = bp - 2 * OWb; row = 1 + (qq >> 1); col = (qq & 1) ? OWb - 1 : 0; }
             *reinterpret_cast<uint4*>(himg + swz_off<COUT>((g * OHb + row) * OWb + col, j)) = make_uint4(0, 0, 0, 0);
         }
-        const float inv_np = 1.0f / float(npix), inv_xw = 1.0f / float(a.XW);
+        const float inv_np = 1.0f / float(npix), inv_xw = 1.0f / float(XW);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = tid + u * THREADS;
             if (i < total) {
                 const int j = i & (CHI - 1), pi_all = i / CHI;
-                const int g = fdiv(pi_all, npix, inv_np), pi = pi_all - g * npix;
-                const int y = fdiv(pi, a.XW, inv_xw), xx = pi - y * a.XW;
+                const int g = qdiv(pi_all, npix, inv_np), pi = pi_all - g * npix;
+                const int y = qdiv(pi, XW, inv_xw), xx = pi - y * XW;
                 *reinterpret_cast<uint4*>(ximg + swz_off<CIN>((g * XHb + y + 1) * XWb + xx + 1, j)) = v[u];
             }
         }
@@ -470,13 +478,13 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
 
     // ---- per-lane geometry: lane r owns output pixel R of each of its M-tiles ---------------------------
     int pr1[MW][3], pr2[MW][3];
-    const float inv_per = 1.0f / float(per), inv_ow = 1.0f / float(a.OW);
+    const float inv_per = 1.0f / float(per), inv_ow = 1.0f / float(OW);
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
         const int R = (mg * MW + mt) * 32 + r;
         const int Rc = R < M ? R : M - 1;
-        const int g = fdiv(Rc, per, inv_per), rem = Rc - g * per;
-        const int oh = fdiv(rem, a.OW, inv_ow), ow = rem - oh * a.OW;
+        const int g = qdiv(Rc, per, inv_per), rem = Rc - g * per;
+        const int oh = qdiv(rem, OW, inv_ow), ow = rem - oh * OW;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             pr1[mt][kh] = (g * XHb + 2 * oh + kh) * XWb + 2 * ow;   // x-image pixel of tap (kh, 0)
@@ -876,8 +884,13 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
             if (m->dtype == COUGH_DTYPE_BF16 && lds <= 160 * 1024 && g * k.oh * k.ow <= mtmax * 32 &&
                 g * k.xh * k.xw * (k.cin / 8) <= 16 * threads) {
                 const dim3 grid((unsigned)((n + g - 1) / g));
-                if (i == 0)
+                // the shipped 90x101 feature image: block inputs 22x25 and 11x13, compiled-in geometry
+                if (i == 0 && k.xh == 22 && k.xw == 25)
+                    hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 1, 3, 4, 22, 25>), grid, dim3(Cfg0::THREADS), lds, st, ra);
+                else if (i == 0)
                     hipLaunchKernelGGL((resblock_bf16_kernel<32, 64, 1, 3, 4>), grid, dim3(Cfg0::THREADS), lds, st, ra);
+                else if (k.xh == 11 && k.xw == 13)
+                    hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 2, 8, 11, 13>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 else
                     hipLaunchKernelGGL((resblock_bf16_kernel<64, 128, 3, 2, 8>), grid, dim3(Cfg1::THREADS), lds, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
@@ -971,11 +984,13 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_fcb), fb);
     }
     if (!err && dtype == COUGH_DTYPE_BF16) {   // the fused block kernels use more than 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 1, 3, 4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 2, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fused[4] = {reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 1, 3, 4>),
+                                reinterpret_cast<const void*>(resblock_bf16_kernel<32, 64, 1, 3, 4, 22, 25>),
+                                reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 2, 8>),
+                                reinterpret_cast<const void*>(resblock_bf16_kernel<64, 128, 3, 2, 8, 11, 13>)};
+        hipError_t e = hipSuccess;
+        for (const void* fn : fused)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("cough_resnet_create: %s", hipGetErrorString(e));
             err = COUGH_EHIP;
