@@ -371,7 +371,11 @@ struct RbCfg {
     static constexpr int THREADS = WAVES * 64;
     static constexpr int KS1 = 9 * CIN / 16, KS2 = (9 * COUT + CIN) / 16;   // 16-wide MFMA k-steps
     static size_t lds_bytes(int XH, int XW, int OH, int OW) {
-        return (size_t(G) * (XH + 2) * (XW + 2) * CIN + size_t(G) * (OH + 2) * (OW + 2) * COUT) * 2;
+        const size_t images = (size_t(G) * (XH + 2) * (XW + 2) * CIN + size_t(G) * (OH + 2) * (OW + 2) * COUT) * 2;
+        // the epilogue re-uses the region as a [MTMAX * 32][COUT + 8] bf16 output tile followed by the head's
+        // reduction scratch: for small images that is the larger of the two
+        const size_t tile = size_t(MTMAX) * 32 * (COUT + 8) * 2 + size_t(WAVES) * 2 * sizeof(float);
+        return images > tile ? images : tile;
     }
 };
 

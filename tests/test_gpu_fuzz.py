@@ -1,0 +1,58 @@
+"""Randomised shapes through every C-ABI entry point that takes a batch: ragged batch sizes, strided inputs, other
+image sizes.  Each case is checked against the CPU oracle (features / logits) or an exact host computation."""
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from cough_detector_amd import synth
+from oracle import cnn as ocnn, featurizer as ofeat, resnet as ores
+from parity import FEAT_TOL, LOGIT_TOL, SHIPPED, feature_errors, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_featuriser_random_batches_and_strides():
+    rng = np.random.default_rng(77)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    pool = synth_batch(1000, 40)
+    ref_pool = ofeat.extract_features_batch(pool, normalize_first=True)
+    for _ in range(12):
+        b = int(rng.integers(1, 41))
+        idx = torch.from_numpy(rng.permutation(40)[:b])
+        stride = 16000 + 4 * int(rng.integers(0, 6))             # row stride must be a multiple of 4
+        buf = torch.zeros((b, stride), device="cuda")
+        buf[:, :16000] = pool[idx].cuda()
+        got = pre.featurize_batch(buf[:, :16000], normalize=True).cpu()
+        mel, rel = feature_errors(got, ref_pool[idx])
+        assert mel < FEAT_TOL and rel < FEAT_TOL, (b, stride, mel, rel)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", LOGIT_TOL)])
+def test_residual_net_random_image_sizes(dtype, tol):
+    """The classifier is fully convolutional: other (F, T) sizes take the unfused kernels (bf16) or the same f32
+    kernels with other shapes."""
+    rng = np.random.default_rng(5)
+    sd = synth.random_state_dict(seed=9)
+    m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    m.cuda()
+    for _ in range(6):
+        b, f, t = int(rng.integers(1, 19)), int(rng.integers(24, 140)), int(rng.integers(24, 140))
+        x = torch.rand((b, 1, f, t), generator=torch.Generator().manual_seed(b * 1000 + f))
+        got = m(x.cuda()).cpu()
+        want = ores.forward(x, sd)
+        assert float((got - want).abs().max()) < tol, (b, f, t)
+
+
+@pytest.mark.parametrize("kind", ["standard", "small"])
+def test_conv_stack_random_image_sizes(cnn_golden, kind):
+    rng = np.random.default_rng(6)
+    sd, _ = cnn_golden[kind]
+    m = cda.create_model(kind, n_mels=90, num_classes=2, in_channels=1)
+    m.load_state_dict(sd)
+    m.cuda()
+    for _ in range(5):
+        b, f, t = int(rng.integers(1, 14)), int(rng.integers(16, 120)), int(rng.integers(16, 120))
+        x = torch.rand((b, 1, f, t), generator=torch.Generator().manual_seed(b * 77 + t))
+        assert float((m(x.cuda()).cpu() - ocnn.FORWARD[kind](x, sd)).abs().max()) < 1e-4, (b, f, t)
