@@ -56,3 +56,25 @@ def test_conv_stack_random_image_sizes(cnn_golden, kind):
         b, f, t = int(rng.integers(1, 14)), int(rng.integers(16, 120)), int(rng.integers(16, 120))
         x = torch.rand((b, 1, f, t), generator=torch.Generator().manual_seed(b * 77 + t))
         assert float((m(x.cuda()).cpu() - ocnn.FORWARD[kind](x, sd)).abs().max()) < 1e-4, (b, f, t)
+
+
+def test_pipeline_every_small_batch_size():
+    """Batches that are not multiples of the block kernels' clip groups (1 and 3 clips per workgroup), of the STFT's
+    8-clip slabs, or of anything else: fused pipeline == featurise -> classify, and both within tolerance of the
+    oracle."""
+    sd = synth.random_state_dict(seed=4)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    wav = synth_batch(2000, 23)
+    ref = ores.forward(ofeat.extract_features_batch(wav, normalize_first=True)[:, None], sd)
+    for dtype, tol in (("bf16", LOGIT_TOL), ("fp32", 1e-4)):
+        m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
+        m.load_state_dict(sd)
+        m.cuda()
+        pipe = cda.CoughPipeline(pre, m)
+        for b in list(range(1, 12)) + [17, 23]:
+            got = pipe(wav[:b].cuda(), normalize=True)
+            two_step = m(pre.featurize_batch(wav[:b].cuda(), normalize=True)[:, None])
+            assert torch.equal(got, two_step), (dtype, b)
+            assert float((got.cpu() - ref[:b]).abs().max()) < tol, (dtype, b)
+            spec = pre.spectrogram_batch(wav[:b].cuda())
+            assert spec.shape == (b, 257, 101) and bool(torch.isfinite(spec).all())
