@@ -78,3 +78,27 @@ def test_pipeline_every_small_batch_size():
             assert float((got.cpu() - ref[:b]).abs().max()) < tol, (dtype, b)
             spec = pre.spectrogram_batch(wav[:b].cuda())
             assert spec.shape == (b, 257, 101) and bool(torch.isfinite(spec).all())
+
+
+def test_stream_detector_reset_and_chunk_length_change():
+    """The captured graphs are re-captured when the chunk length changes and survive reset(); results always equal
+    the eager path's."""
+    from cough_detector_amd.streaming import MultiStreamDetector
+    sd = synth.random_state_dict(seed=8)
+    streams = np.stack([synth.make_stream(60 + s, 5.0) for s in range(4)])
+    out = []
+    for use_graphs in (True, False):
+        m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        m.load_state_dict(sd)
+        det = MultiStreamDetector(m, 4, confidence_threshold=2.0, clock=lambda: 0.0, use_graphs=use_graphs)
+        log = []
+        for chunk in (1600, 800, 4000):
+            det.reset()
+            for p in det.window_probs:
+                p.clear()
+            for i in range(0, 40000, chunk):
+                det.push(streams[:, i:i + chunk])
+            log.append([list(p) for p in det.window_probs])
+        out.append(log)
+    assert out[0] == out[1]
+    assert all(len(p) == 7 for p in out[0][0])          # (40000 - 16000) / 4000 + 1 windows per stream
