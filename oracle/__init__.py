@@ -16,12 +16,18 @@ Contents
                 ``ResidualBlock`` (``/root/reference/src/model.py:210-293``).
 ``engine``      restatement of the sliding-window loop
                 (``/root/reference/src/inference.py:165-247``).
+``cnn``         functional restatement of ``CoughDetector`` / ``CoughDetectorSmall``
+                (``/root/reference/src/model.py:11-207``).
+``augmentation`` restatement of ``SpecAugment`` (``/root/reference/src/augmentation.py:271-331``).
 
 Pinning status
 --------------
 * ``resnet``: PINNED.  ``/root/reference/src/model.py`` imports in the build
   container (torch only); ``oracle/make_golden.py`` runs it and commits
   weights / inputs / per-layer activations / logits under ``tests/golden/``.
+* ``cnn``: PINNED the same way (``oracle/make_golden_cnn.py`` -> ``tests/golden/cnn_golden.npz``).
+* ``augmentation``, and the resampler / PCEN / spectral-contrast / centroid parts of ``featurizer``:
+  **PARITY UNPINNED** (torchaudio algorithms restated from their published form; no reference vectors).
 * ``featurizer``: **PARITY UNPINNED against torchaudio.**  The arithmetic lives
   in ``torchaudio`` (``requirements.txt:3``: ``torchaudio>=2.0.0``, no lock
   file) which is neither under ``/root/reference`` nor installed nor
