@@ -190,6 +190,131 @@ __global__ __launch_bounds__(256) void cnn_conv_kernel(CnnConvArgs<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ dense blocks from an LDS image
+// bf16, CIN in {16, 32, 64}: one workgroup = one band of conv-output rows of one clip.  The band's input rows (+ one
+// row / column of zero border each side) are staged ONCE into an XOR-swizzled LDS image, so every input pixel leaves
+// L2 once instead of nine times (the im2col GEMM above re-gathers it per tap, and with N = 64 that traffic, not
+// the MFMAs, sets its speed); all 9 * CIN / 16 k-steps then run out of LDS.  Weights arrive as MFMA fragments
+// [k-step][n-tile][64 lanes][8] straight from L2 (every wave of every workgroup walks the same 36-74 KB stream).
+// GEMM rows are ordered (pool window, dy, dx) as in cnn_conv_kernel; wave w owns tiles w*MW .. w*MW + MW - 1.
+struct CnnLdsArgs {
+    const bf16_t* in;     // NHWC [B][H][W][CIN]
+    const bf16_t* wf;     // [9 * CIN / 16][NT][64][8]
+    const float* bias;
+    bf16_t* out;          // NHWC [B][OH][OW][32 * NT]
+    int H, W, OH, OW;     // OH x OW: output size (pooled when POOL)
+    int band_rows;        // output rows per workgroup
+    int n_bands;          // workgroups per clip
+};
+
+template <int CIN, int NT, int MW, bool POOL>
+__global__ __launch_bounds__(256) void cnn_conv_lds_kernel(CnnLdsArgs a) {
+    constexpr int CH = CIN / 8, KSTEPS = 9 * CIN / 16, N = 32 * NT, S = POOL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.x / a.n_bands, band = blockIdx.x - clip * a.n_bands;
+    const int o0 = band * a.band_rows;                                   // first output row of the band
+    const int orows = a.OH - o0 < a.band_rows ? a.OH - o0 : a.band_rows; // output rows in this band
+    const int crow0 = S * o0, crows = S * orows;                         // conv rows [crow0, crow0 + crows)
+    const int Wb = a.W + 2, irows = crows + 2;                           // image: conv rows - 1 .. + crows, cols -1 .. W
+
+    // ---- stage (zero outside the input) ----
+    {
+        const bf16_t* src = a.in + (long long)clip * a.H * a.W * CIN;
+        const int total = irows * Wb * CH;
+        const float inv_wb = 1.0f / float(Wb);
+        for (int i = tid; i < total; i += 256) {
+            const int j = i & (CH - 1), P = i / CH;
+            int rr = int(float(P) * inv_wb);
+            rr -= (rr * Wb > P);
+            rr += ((rr + 1) * Wb <= P);
+            const int cc = P - rr * Wb;
+            const int iy = crow0 - 1 + rr, ix = cc - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const uint4*>(src + ((long long)iy * a.W + ix) * CIN + 8 * j);
+            *reinterpret_cast<uint4*>(img + swz_off<CIN>(P, j)) = v;
+        }
+    }
+    __syncthreads();
+
+    const int M = orows * a.OW * (POOL ? 4 : 1);   // GEMM rows of the band
+    if (wave * MW * 32 >= M) return;               // whole wave beyond the band (no barrier follows)
+    int pix[MW];                                   // LDS pixel of tap (0, 0) of this lane's row in each tile
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        int m = (wave * MW + mt) * 32 + r;
+        if (m >= M) m = M - 1;
+        int y, x;
+        if constexpr (POOL) {
+            const int win = m >> 2, q = m & 3, py = win / a.OW, px = win - py * a.OW;
+            y = 2 * py + (q >> 1);
+            x = 2 * px + (q & 1);
+        } else {
+            y = m / a.OW;
+            x = m - y * a.OW;
+        }
+        pix[mt] = y * Wb + x;                      // image row y = conv row crow0 + y - 1 + kh, column x - 1 + kw
+    }
+    f32x16 acc[MW][NT];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x16{0};
+
+    const bf16_t* wl = a.wf + lane * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int c16 = 0; c16 < CIN / 16; ++c16) {
+            const int s = tap * (CIN / 16) + c16;
+            bf16x8 bfr[NT], af[MW];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const bf16x8*>(wl + (size_t(s) * NT + nt) * 512);
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt) {
+                const int P = pix[mt] + kh * Wb + kw;
+                af[mt] = *reinterpret_cast<const bf16x8*>(img + swz_off<CIN>(P, 2 * c16 + h));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    static_assert(KSTEPS == 9 * (CIN / 16), "k-steps");
+
+    // epilogue: register `reg` of lane (r, h) is GEMM row (reg & 3) + 8 * (reg >> 2) + 4 * h of the tile, column r
+    bf16_t* o = a.out + ((long long)clip * a.OH + o0) * a.OW * N;
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        const int m0 = (wave * MW + mt) * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + r;
+            const float bn = a.bias[n];
+            if constexpr (POOL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int win = (m0 >> 2) + 2 * g + h;
+                    const float v = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]),
+                                          fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
+                    if (win * 4 < M) o[(long long)win * N + n] = f2bf(fmaxf(v + bn, 0.f));
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int mo = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (mo < M) o[(long long)mo * N + n] = f2bf(fmaxf(acc[mt][nt][reg] + bn, 0.f));
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ head
 // one workgroup per clip: thread c < C averages channel c; thread j < HID forms hidden unit j; wave 0 the logits
 template <typename T>
@@ -208,10 +333,9 @@ __global__ __launch_bounds__(256) void cnn_tail_kernel(const T* __restrict__ act
         v[tid] = s / float(HW);
     }
     __syncthreads();
-    if (tid < HID) {
-        const float* wr = w1 + (long long)tid * C;
+    if (tid < HID) {   // w1 is stored transposed, [C][HID]: the lanes of a wave read consecutive addresses
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s = fmaf(wr[c], v[c], s);
+        for (int c = 0; c < C; ++c) s = fmaf(w1[c * HID + tid], v[c], s);
         hid[tid] = fmaxf(s + b1[tid], 0.f);
     }
     __syncthreads();
@@ -259,6 +383,7 @@ struct cough_cnn {
         float* d_b;
         int ktot;       // row pitch of d_w: ks*ks*cin, padded to a multiple of 64 for the LDS-staged bf16 GEMM
         bool gemm;      // bf16, cin % 32 == 0, cout % 64 == 0: conv_gemm_bf16_kernel
+        cough::bf16_t* d_wfrag;   // bf16 (16->32), (32->64), (64->128) blocks: MFMA fragments for cnn_conv_lds_kernel
     };
     int dtype;
     size_t esize;
@@ -314,6 +439,31 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
             else
                 hipLaunchKernelGGL((cnn_first_kernel<T, false>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
                                    static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
+        } else if (l.d_wfrag) {
+            if constexpr (sizeof(T) == 2) {
+                // band of output rows per workgroup: 4 waves x MW tiles x 32 GEMM rows (x4 rows per output when pooled)
+                const int mw = l.cin == 64 ? 2 : 4, per_out = l.pool == 2 ? 4 : 1;
+                int band = (4 * mw * 32) / (per_out * s.w);
+                if (band > s.h) band = s.h;
+                const int n_bands = (s.h + band - 1) / band;
+                const size_t lds = size_t((l.pool == 2 ? 2 : 1) * band + 2) * (cw + 2) * l.cin * 2;
+                if (band >= 1 && lds <= 64 * 1024) {
+                    CnnLdsArgs a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands};
+                    const dim3 grid((unsigned)(n * n_bands));
+#define COUGH_LDS_LAUNCH(CIN, NT, MW)                                                                            \
+    do {                                                                                                         \
+        if (l.pool == 2) hipLaunchKernelGGL((cnn_conv_lds_kernel<CIN, NT, MW, true>), grid, dim3(256), lds, st, a);  \
+        else hipLaunchKernelGGL((cnn_conv_lds_kernel<CIN, NT, MW, false>), grid, dim3(256), lds, st, a);             \
+    } while (0)
+                    if (l.cin == 16) COUGH_LDS_LAUNCH(16, 1, 4);
+                    else if (l.cin == 32) COUGH_LDS_LAUNCH(32, 2, 4);
+                    else COUGH_LDS_LAUNCH(64, 4, 2);
+#undef COUGH_LDS_LAUNCH
+                } else {
+                    set_error("cough_cnn_forward: image %dx%d too wide for the LDS-image convolution", ch, cw);
+                    return COUGH_EUNSUPPORTED;
+                }
+            }
         } else if (l.gemm) {
             if constexpr (sizeof(T) == 2) {
                 ConvArgs<bf16_t> a{};
@@ -374,6 +524,7 @@ extern "C" void cough_cnn_destroy(cough_cnn* m) {
     for (auto& l : m->layers) {
         (void)hipFree(l.d_w);
         (void)hipFree(l.d_b);
+        (void)hipFree(l.d_wfrag);
     }
     (void)hipFree(m->d_w1);
     (void)hipFree(m->d_b1);
@@ -436,7 +587,7 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
             for (int k = 0; k < K; ++k) wd[size_t(n) * K + k] *= scale;
             bd[n] = (bacc - double(p.bn_mean[n])) * scale + double(p.bn_b[n]);
         }
-        cough_cnn::Layer l{Cc, N, 3, bk.pool, nullptr, nullptr, K, false};
+        cough_cnn::Layer l{Cc, N, 3, bk.pool, nullptr, nullptr, K, false, nullptr};
         l.gemm = i > 0 && m->esize == 2 && Cc % 32 == 0 && N % 64 == 0;
         if (l.gemm) l.ktot = ((K + 63) / 64) * 64;
         std::vector<float> bf(N);
@@ -456,12 +607,29 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
                 for (int k = 0; k < K; ++k) wb[size_t(n) * l.ktot + k] = f2bf_host(float(wd[size_t(n) * K + k]));
             err = cnn_upload(&l.d_w, wb);
         }
+        if (!err && i > 0 && m->esize == 2 && ((Cc == 16 && N == 32) || (Cc == 32 && N == 64) || (Cc == 64 && N == 128))) {
+            // fragment order of cnn_conv_lds_kernel: lane (r, h) of (k-step s, n-tile t) holds W[32t + r][16s + 8h ..+7]
+            const int ks = K / 16, nt = N / 32;
+            std::vector<bf16_t> wfr(size_t(ks) * nt * 512);
+            for (int st = 0; st < ks; ++st)
+                for (int t = 0; t < nt; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int jj = 0; jj < 8; ++jj)
+                            wfr[((size_t(st) * nt + t) * 64 + lane) * 8 + jj] =
+                                f2bf_host(float(wd[size_t(32 * t + (lane & 31)) * K + 16 * st + 8 * (lane >> 5) + jj]));
+            err = cnn_upload(reinterpret_cast<void**>(&l.d_wfrag), wfr);
+        }
         if (!err) err = cnn_upload(reinterpret_cast<void**>(&l.d_b), bf);
         m->layers.push_back(l);
     }
     m->feat_c = w->blocks[w->n_blocks - 1].cout;
     m->hidden = w->hidden;
-    if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_w1), std::vector<float>(w->fc1_w, w->fc1_w + size_t(m->hidden) * m->feat_c));
+    if (!err) {   // fc1 transposed to [C][hidden] for coalesced reads in the head kernel
+        std::vector<float> w1t(size_t(m->hidden) * m->feat_c);
+        for (int jx = 0; jx < m->hidden; ++jx)
+            for (int c = 0; c < m->feat_c; ++c) w1t[size_t(c) * m->hidden + jx] = w->fc1_w[size_t(jx) * m->feat_c + c];
+        err = cnn_upload(reinterpret_cast<void**>(&m->d_w1), w1t);
+    }
     if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_b1), std::vector<float>(w->fc1_b, w->fc1_b + m->hidden));
     if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_w2), std::vector<float>(w->fc2_w, w->fc2_w + size_t(2) * m->hidden));
     if (!err) err = cnn_upload(reinterpret_cast<void**>(&m->d_b2), std::vector<float>(w->fc2_b, w->fc2_b + 2));

@@ -33,5 +33,13 @@ template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
 
+// LDS image of NHWC bf16 pixels: the 16-byte channel chunks of a pixel are XOR-swizzled by the pixel index so that a
+// ds_read_b128 of one chunk of 16 consecutive pixels touches 16 different 16-byte slots of the 256-byte bank row.
+template <int C>
+__device__ __forceinline__ int swz_off(int P, int j) {   // bf16 offset of 16-byte chunk j of pixel P
+    constexpr int CH = C / 8, PPR = 16 / CH;             // chunks per pixel, pixels per 256-byte bank row
+    return P * C + 8 * (j ^ ((P / PPR) & (CH - 1)));
+}
+
 }  // namespace
 }  // namespace cough

@@ -329,11 +329,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
 // stream global/L2 -> registers (two 64-wide chunks ahead) -> a two-stage LDS ring shared by all waves.
 // GEMM view per workgroup: M = G*OH*OW output pixels (32-row MFMA tiles), N = COUT, K = 9*CIN then
 // 9*COUT + CIN.  Wave (mg, ng) owns MW M-tiles x NW N-tiles.
-template <int C>
-__device__ __forceinline__ int swz_off(int P, int j) {   // bf16 offset of 16-byte chunk j of pixel P
-    constexpr int CH = C / 8, PPR = 16 / CH;             // chunks per pixel, pixels per 256-byte bank row
-    return P * C + 8 * (j ^ ((P / PPR) & (CH - 1)));
-}
 
 #ifdef COUGH_K1_STAMPS
 // diagnostic build only (tools/rb_stamps.py): per-workgroup s_memtime at phase boundaries
