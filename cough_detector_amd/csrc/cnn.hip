@@ -20,6 +20,7 @@
 //                          never computed)
 //   head                   cnn_tail_kernel: mean over H x W -> Linear -> ReLU -> Linear -> softmax / argmax
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void cnn_conv_kernel(CnnConvArgs<T> a) {
 // the MFMAs, sets its speed); all 9 * CIN / 16 k-steps then run out of LDS.  Weights arrive as MFMA fragments
 // [k-step][n-tile][64 lanes][8] straight from L2 (every wave of every workgroup walks the same 36-74 KB stream).
 // GEMM rows are ordered (pool window, dy, dx) as in cnn_conv_kernel; wave w owns tiles w*MW .. w*MW + MW - 1.
+constexpr int CNN_LDS_UNP = 12;   // 16-byte pieces of the LDS image per thread (image <= 48 KB)
 struct CnnLdsArgs {
     const bf16_t* in;     // NHWC [B][H][W][CIN]
     const bf16_t* wf;     // [9 * CIN / 16][NT][64][8]
@@ -219,23 +221,31 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_kernel(CnnLdsArgs a) {
     const int crow0 = S * o0, crows = S * orows;                         // conv rows [crow0, crow0 + crows)
     const int Wb = a.W + 2, irows = crows + 2;                           // image: conv rows - 1 .. + crows, cols -1 .. W
 
-    // ---- stage (zero outside the input) ----
+    // ---- stage (zero outside the input): every 16-byte piece is requested before the first one is written to
+    // LDS, so the band pays one global-memory latency, not one per piece (host: <= UNP * 256 pieces) ----
     {
         const bf16_t* src = a.in + (long long)clip * a.H * a.W * CIN;
         const int total = irows * Wb * CH;
         const float inv_wb = 1.0f / float(Wb);
-        for (int i = tid; i < total; i += 256) {
+        uint4 v[CNN_LDS_UNP];
+        int dst[CNN_LDS_UNP];
+#pragma unroll
+        for (int u = 0; u < CNN_LDS_UNP; ++u) {
+            const int i = tid + u * 256;
             const int j = i & (CH - 1), P = i / CH;
             int rr = int(float(P) * inv_wb);
             rr -= (rr * Wb > P);
             rr += ((rr + 1) * Wb <= P);
             const int cc = P - rr * Wb;
             const int iy = crow0 - 1 + rr, ix = cc - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = *reinterpret_cast<const uint4*>(src + ((long long)iy * a.W + ix) * CIN + 8 * j);
-            *reinterpret_cast<uint4*>(img + swz_off<CIN>(P, j)) = v;
+            v[u] = make_uint4(0, 0, 0, 0);
+            dst[u] = i < total ? swz_off<CIN>(P, j) : -1;
+            if (i < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v[u] = *reinterpret_cast<const uint4*>(src + ((long long)iy * a.W + ix) * CIN + 8 * j);
         }
+#pragma unroll
+        for (int u = 0; u < CNN_LDS_UNP; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4*>(img + dst[u]) = v[u];
     }
     __syncthreads();
 
@@ -263,28 +273,46 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_kernel(CnnLdsArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x16{0};
 
+    // Software pipeline over the fully unrolled k-steps (compile-time taps): weight fragments run D k-steps ahead in
+    // a register ring, activation fragments one k-step ahead; each (ds_read, MFMA group) pair is pinned with
+    // scheduling barriers -- left alone hipcc issues every load right before its use and each k-step pays the
+    // full L2 / LDS latency.
     const bf16_t* wl = a.wf + lane * 8;
+    constexpr int D = (NT <= 2) ? 6 : 3;
+    bf16x8 wring[D][NT], af[2][MW];
+    auto wload = [&](int s, bf16x8 (&dst)[NT]) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int kh = tap / 3, kw = tap - 3 * kh;
+        for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const bf16x8*>(wl + (size_t(s) * NT + nt) * 512);
+    };
+    auto aload = [&](auto sc, int mt) -> bf16x8 {
+        constexpr int s = decltype(sc)::value, tap = s / (CIN / 16), c16 = s % (CIN / 16), kh = tap / 3, kw = tap % 3;
+        const int P = pix[mt] + kh * Wb + kw;
+        return *reinterpret_cast<const bf16x8*>(img + swz_off<CIN>(P, 2 * c16 + h));
+    };
 #pragma unroll
-        for (int c16 = 0; c16 < CIN / 16; ++c16) {
-            const int s = tap * (CIN / 16) + c16;
-            bf16x8 bfr[NT], af[MW];
+    for (int i = 0; i < D; ++i) wload(i, wring[i]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const bf16x8*>(wl + (size_t(s) * NT + nt) * 512);
+    for (int mt = 0; mt < MW; ++mt) af[0][mt] = aload(std::integral_constant<int, 0>{}, mt);
+    auto step = [&]<int s>() {
+        bf16x8 bw[NT];
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt) {
-                const int P = pix[mt] + kh * Wb + kw;
-                af[mt] = *reinterpret_cast<const bf16x8*>(img + swz_off<CIN>(P, 2 * c16 + h));
+        for (int nt = 0; nt < NT; ++nt) bw[nt] = wring[s % D][nt];
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            if constexpr (s + 1 < KSTEPS) af[(s + 1) & 1][mt] = aload(std::integral_constant<int, s + 1>{}, mt);
+            if constexpr (s + D < KSTEPS) {
+                if (mt == 0) wload(s + D, wring[s % D]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt], bw[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+        (step.template operator()<Ss>(), ...);
+    }(std::make_integer_sequence<int, KSTEPS>{});
     static_assert(KSTEPS == 9 * (CIN / 16), "k-steps");
 
     // epilogue: register `reg` of lane (r, h) is GEMM row (reg & 3) + 8 * (reg >> 2) + 4 * h of the tile, column r
@@ -447,7 +475,7 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
                 if (band > s.h) band = s.h;
                 const int n_bands = (s.h + band - 1) / band;
                 const size_t lds = size_t((l.pool == 2 ? 2 : 1) * band + 2) * (cw + 2) * l.cin * 2;
-                if (band >= 1 && lds <= 64 * 1024) {
+                if (band >= 1 && lds <= size_t(CNN_LDS_UNP) * 256 * 16) {
                     CnnLdsArgs a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands};
                     const dim3 grid((unsigned)(n * n_bands));
 #define COUGH_LDS_LAUNCH(CIN, NT, MW)                                                                            \
