@@ -426,6 +426,14 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
     bf16x8 bring[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) bring[i] = wfrag(i);
+    // folded biases of this wave's 32 channels (lane half h: 4 of every 8), fetched now: loaded where they are used,
+    // behind the scheduling barriers of the k-loop, each fetch would expose a full global-memory latency
+    float4 bias1[4], bias2[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        bias1[gq] = *reinterpret_cast<const float4*>(a.b1 + ng * 32 + 8 * gq + 4 * h);
+        bias2[gq] = *reinterpret_cast<const float4*>(a.b2 + ng * 32 + 8 * gq + 4 * h);
+    }
 
     // ---- stage: the x image of the G clips is one linear run of 16-byte pieces: every load is issued first,
     // the borders of both LDS images are zeroed while the data is in flight, then the pieces are scattered to
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int n0 = ng * 32 + 8 * gq + 4 * h;
-                        const float4 bb = *reinterpret_cast<const float4*>(a.b1 + n0);
+                        const float4 bb = bias1[gq];
                         const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
                                                     fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
                         if (rok) *reinterpret_cast<uint2*>(himg + swz_off<COUT>(P, n0 >> 3) + (n0 & 7)) = pk;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int n0 = ng * 32 + 8 * gq + 4 * h;
-                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
+                const float4 bb = bias2[gq];
                 const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
                                             fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
                 *reinterpret_cast<uint2*>(otile + R * OPITCH + n0) = pk;
