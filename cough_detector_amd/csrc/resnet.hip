@@ -434,6 +434,13 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
         bias1[gq] = *reinterpret_cast<const float4*>(a.b1 + ng * 32 + 8 * gq + 4 * h);
         bias2[gq] = *reinterpret_cast<const float4*>(a.b2 + ng * 32 + 8 * gq + 4 * h);
     }
+    float fw0 = 0.f, fw1 = 0.f, fb0 = 0.f, fb1 = 0.f;   // fused head (block 1): Linear(128, 2) row pair of channel tid & 127
+    if constexpr (COUT == 128) {
+        if (a.fcw != nullptr) {
+            fw0 = a.fcw[tid & 127]; fw1 = a.fcw[128 + (tid & 127)];
+            fb0 = a.fcb[0]; fb1 = a.fcb[1];
+        }
+    }
 
     // ---- stage: the x image of the G clips is one linear run of 16-byte pieces: every load is issued first,
     // the borders of both LDS images are zeroed while the data is in flight, then the pieces are scattered to
@@ -628,16 +635,16 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
 #pragma unroll 6
                     for (int i = 0; i < per; ++i) sum += bf2f(otile[(g * per + i) * OPITCH + c]);
                     const float mean = sum / float(per);
-                    l0 = wave_sum(mean * a.fcw[c]);
-                    l1 = wave_sum(mean * a.fcw[128 + c]);
+                    l0 = wave_sum(mean * fw0);
+                    l1 = wave_sum(mean * fw1);
                 }
                 __syncthreads();
                 if (lane == 0) { hred[wave * 2] = l0; hred[wave * 2 + 1] = l1; }
                 __syncthreads();
                 if (g < G && c == 0 && clip0 + g < a.n_clips) {
                     const int w0 = (tid >> 7) * 2;   // the clip's two waves
-                    l0 = hred[w0 * 2] + hred[(w0 + 1) * 2] + a.fcb[0];
-                    l1 = hred[w0 * 2 + 1] + hred[(w0 + 1) * 2 + 1] + a.fcb[1];
+                    l0 = hred[w0 * 2] + hred[(w0 + 1) * 2] + fb0;
+                    l1 = hred[w0 * 2 + 1] + hred[(w0 + 1) * 2 + 1] + fb1;
                     const long long b = clip0 + g;
                     a.logits[b * 2] = l0;
                     a.logits[b * 2 + 1] = l1;
