@@ -110,7 +110,7 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return *reinterpret_cast<uint16_t*>(&b);
 }
 // geometry of the fused stem for the 90x101 feature image (resnet.hip: stem_bf16_kernel / stem_lds)
-constexpr int ST_H = 90, ST_W = NFRAMES, ST_P1H = 22, ST_P1W = 25, ST_ROWS = 94, ST_PITCH = 106;
+constexpr int ST_H = 90, ST_P1H = 22, ST_P1W = 25, ST_ROWS = 94, ST_PITCH = 106;   // image width = NFRAMES
 constexpr int ST_PER = ST_P1H * ST_P1W, ST_TILES = (ST_PER + 7) / 8;
 static_assert(size_t(ST_ROWS) * ST_PITCH * 2 <= LDS_MEL, "the bf16 feature image aliases the dB buffer");
 

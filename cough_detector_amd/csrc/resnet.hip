@@ -253,7 +253,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
             const bool ok = rowok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
             const T* ap = a.in + (((long long)b * a.H + (ok ? ih : 0)) * a.W + (ok ? iw : 0)) * a.C;
             if constexpr (sizeof(T) == 4) {
-#pragma unroll 2
                 for (int c0 = 0; c0 < a.C; c0 += 8) {
                     float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (ok) av = *reinterpret_cast<const float4*>(ap + c0 + 4 * h);
@@ -267,7 +266,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
                     }
                 }
             } else {
-#pragma unroll 2
                 for (int c0 = 0; c0 < a.C; c0 += 16) {
                     bf16x8 av = {0};
                     if (ok) av = *reinterpret_cast<const bf16x8*>(ap + c0 + 8 * h);

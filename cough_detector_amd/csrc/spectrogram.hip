@@ -28,7 +28,7 @@ constexpr int PADL = NFFT / 2;
 constexpr int THREADS = 256, WAVES = 4, FPW = 4;
 constexpr int NGROUP = (NFRAMES + FPW - 1) / FPW;           // 26 groups of 4 frames
 constexpr int NCHUNK = 4;
-__device__ constexpr int CHUNK_G0[NCHUNK + 1] = {0, 7, 14, 20, 26};   // first group of each chunk: every wave has 1-2 groups
+__device__ constexpr int CHUNK_G0[NCHUNK + 1] = {0, 7, 14, 20, NGROUP};   // first group of each chunk: every wave has 1-2 groups
 constexpr int CHUNK_MAX = 7 * FPW;                          // frames staged per item (<= 28)
 constexpr int XROW = 17, XFRAME = 16 * XROW;
 constexpr int FIRST_PLAIN = 2, LAST_PLAIN = 98;             // frames whose 512 samples lie inside the clip
