@@ -610,7 +610,7 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
         }
     }
     __syncthreads();
-    {
+    if (a.out != nullptr) {   // nullptr: the block output is only consumed by the fused head (pipeline: no parity tap)
         const int mvalid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * per;
         uint4* o = reinterpret_cast<uint4*>(a.out + (long long)clip0 * per * COUT);
         for (int p = tid; p < mvalid * CHO; p += THREADS) {
@@ -890,6 +890,8 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
             ra.wf2 = m->d_wfrag[k.s2]; ra.b2 = m->d_b[k.s2];
             ra.out = reinterpret_cast<bf16_t*>(k.out);
             if (i == 1) { ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds; }
+            if (i == 1 && stem_done) ra.out = nullptr;   // pipeline: nobody reads a3 (the activation tap,
+                                                         // cough_resnet_read_activation, belongs to cough_resnet_forward)
             const size_t lds = i == 0 ? Cfg0::lds_bytes(k.xh, k.xw, k.oh, k.ow) : Cfg1::lds_bytes(k.xh, k.xw, k.oh, k.ow);
             const int g = i == 0 ? 1 : 3, mtmax = i == 0 ? Cfg0::MTMAX : Cfg1::MTMAX;
             const int threads = i == 0 ? Cfg0::THREADS : Cfg1::THREADS;
