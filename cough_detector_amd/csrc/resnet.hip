@@ -508,107 +508,114 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
     __syncthreads();
     RB_STAMP(2);
 
-    f32x16 acc[MW];
-#pragma unroll
-    for (int mt = 0; mt < MW; ++mt) acc[mt] = f32x16{0};
+    constexpr int OPITCH = COUT + 8;   // bf16 elements per LDS row of the output tile
+    bf16_t* otile = ximg;              // the epilogue's output tile lies over the (then dead) x image
+    // The compute part is instantiated for MW and MW - 1 tiles per wave: a wave whose last tile lies entirely beyond
+    // the M valid rows (block 0: 143 rows = 4.5 tiles for 2 x 3) runs the shorter body -- one wave-uniform choice up
+    // front instead of a branch around every MFMA (that version doubled the kernel time).
+    auto body = [&]<int MWX>() {
+        f32x16 acc[MWX];
+    #pragma unroll
+        for (int mt = 0; mt < MWX; ++mt) acc[mt] = f32x16{0};
 
-    // Activation fragments of k-step s (compile-time at every call site).  The pixel-dependent part of the
-    // swizzled LDS address -- base pointer of the tap's pixel and hs = h ^ swizzle(pixel) -- is computed once
-    // per (tile, tap) when the first k-step of a tap is fetched; every further k-step of that tap costs one
-    // xor and one shift-add per fragment.
-    const bf16_t* tbase[MW];
-    int ths[MW];
-    auto afrag1 = [&](auto sc, int mt) -> bf16x8 {
-        constexpr int s = decltype(sc)::value;
-        constexpr bool conv1 = s < KS1;
-        constexpr int kg = conv1 ? s * 16 : (s - KS1) * 16;
-        constexpr bool proj = !conv1 && kg >= K2M;
-        constexpr int C = (conv1 || proj) ? CIN : COUT, CH = C / 8;
-        constexpr int kt = proj ? kg - K2M : kg;                 // k inside this operand
-        constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
-        if constexpr (c16 == 0) {                                // first k-step of a tap: new pixel
-            const int P = ((conv1 || proj) ? pr1[mt][kh] : pr2[mt][kh]) + kw;
-            ths[mt] = h ^ ((P / (16 / CH)) & (CH - 1));
-            tbase[mt] = ((conv1 || proj) ? ximg : himg) + P * C;
-        }
-        return *reinterpret_cast<const bf16x8*>(tbase[mt] + 8 * ((2 * c16) ^ ths[mt]));
-    };
-    auto afrags = [&](auto sc, bf16x8 (&dst)[MW]) {
-#pragma unroll
-        for (int mt = 0; mt < MW; ++mt) dst[mt] = afrag1(sc, mt);
-    };
+        // Activation fragments of k-step s (compile-time at every call site).  The pixel-dependent part of the
+        // swizzled LDS address -- base pointer of the tap's pixel and hs = h ^ swizzle(pixel) -- is computed once
+        // per (tile, tap) when the first k-step of a tap is fetched; every further k-step of that tap costs one
+        // xor and one shift-add per fragment.
+        const bf16_t* tbase[MWX];
+        int ths[MWX];
+        auto afrag1 = [&](auto sc, int mt) -> bf16x8 {
+            constexpr int s = decltype(sc)::value;
+            constexpr bool conv1 = s < KS1;
+            constexpr int kg = conv1 ? s * 16 : (s - KS1) * 16;
+            constexpr bool proj = !conv1 && kg >= K2M;
+            constexpr int C = (conv1 || proj) ? CIN : COUT, CH = C / 8;
+            constexpr int kt = proj ? kg - K2M : kg;                 // k inside this operand
+            constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
+            if constexpr (c16 == 0) {                                // first k-step of a tap: new pixel
+                const int P = ((conv1 || proj) ? pr1[mt][kh] : pr2[mt][kh]) + kw;
+                ths[mt] = h ^ ((P / (16 / CH)) & (CH - 1));
+                tbase[mt] = ((conv1 || proj) ? ximg : himg) + P * C;
+            }
+            return *reinterpret_cast<const bf16x8*>(tbase[mt] + 8 * ((2 * c16) ^ ths[mt]));
+        };
+        auto afrags = [&](auto sc, bf16x8 (&dst)[MWX]) {
+    #pragma unroll
+            for (int mt = 0; mt < MWX; ++mt) dst[mt] = afrag1(sc, mt);
+        };
 
-    bf16x8 af[2][MW];
-    if (active) afrags(std::integral_constant<int, 0>{}, af[0]);
+        bf16x8 af[2][MWX];
+        if (active) afrags(std::integral_constant<int, 0>{}, af[0]);
 
-    auto step = [&]<int s>() {
-        if constexpr (s == KS1) {
-            RB_STAMP(3);
-            // ---- h = ReLU(conv1 + b1) -> interior of the h image (its border was zeroed while staging) ----
-            if (active) {
-#pragma unroll
-                for (int mt = 0; mt < MW; ++mt) {
-                    const bool rok = (mg * MW + mt) * 32 + r < M;
-                    const int P = pr2[mt][1] + 1;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int n0 = ng * 32 + 8 * gq + 4 * h;
-                        const float4 bb = bias1[gq];
-                        const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
-                                                    fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
-                        if (rok) *reinterpret_cast<uint2*>(himg + swz_off<COUT>(P, n0 >> 3) + (n0 & 7)) = pk;
+        auto step = [&]<int s>() {
+            if constexpr (s == KS1) {
+                RB_STAMP(3);
+                // ---- h = ReLU(conv1 + b1) -> interior of the h image (its border was zeroed while staging) ----
+                if (active) {
+    #pragma unroll
+                    for (int mt = 0; mt < MWX; ++mt) {
+                        const bool rok = (mg * MW + mt) * 32 + r < M;
+                        const int P = pr2[mt][1] + 1;
+    #pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int n0 = ng * 32 + 8 * gq + 4 * h;
+                            const float4 bb = bias1[gq];
+                            const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
+                                                        fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
+                            if (rok) *reinterpret_cast<uint2*>(himg + swz_off<COUT>(P, n0 >> 3) + (n0 & 7)) = pk;
+                        }
+                        acc[mt] = f32x16{0};
                     }
-                    acc[mt] = f32x16{0};
+                }
+                __syncthreads();
+                RB_STAMP(4);
+                if (active) afrags(std::integral_constant<int, s>{}, af[s & 1]);
+            }
+            if (active) {
+                // Software pipeline, pinned with scheduling barriers: ahead of MFMA mt of this step sit the address
+                // math + ds_read of the NEXT step's fragment mt (and, once per step, the weight load D steps ahead).
+                // Each pair issues in the ~24 cycles an MFMA leaves free; left alone, the scheduler sinks every
+                // ds_read next to its MFMA (ds_read -> lgkmcnt(0) -> mfma) and each MFMA pays the full LDS latency.
+                const bf16x8 bw = bring[s % D];
+    #pragma unroll
+                for (int mt = 0; mt < MWX; ++mt) {
+                    if constexpr (s + 1 < KS && s + 1 != KS1)
+                        af[(s + 1) & 1][mt] = afrag1(std::integral_constant<int, s + 1>{}, mt);
+                    if constexpr (s + D < KS) {
+                        if (mt == 0) bring[s % D] = wfrag(s + D);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, af[s & 1][mt], acc[mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();
-            RB_STAMP(4);
-            if (active) afrags(std::integral_constant<int, s>{}, af[s & 1]);
-        }
+        };
+        [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+            (step.template operator()<Ss>(), ...);
+        }(std::make_integer_sequence<int, KS>{});
+
+        RB_STAMP(5);
+        // ---- epilogue: out = ReLU(conv2 + projection + b2).  The accumulators go to a bf16 [pixel][COUT] tile in
+        // LDS (over the dead x image; rows padded by 16 B), then the workgroup copies the tile -- which is one
+        // contiguous run of NHWC output -- to global with 16-byte-per-lane coalesced stores. ----------------------
+        __syncthreads();                   // every wave is done reading the x / h images
         if (active) {
-            // Software pipeline, pinned with scheduling barriers: ahead of MFMA mt of this step sit the address
-            // math + ds_read of the NEXT step's fragment mt (and, once per step, the weight load D steps ahead).
-            // Each pair issues in the ~24 cycles an MFMA leaves free; left alone, the scheduler sinks every
-            // ds_read next to its MFMA (ds_read -> lgkmcnt(0) -> mfma) and each MFMA pays the full LDS latency.
-            const bf16x8 bw = bring[s % D];
-#pragma unroll
-            for (int mt = 0; mt < MW; ++mt) {
-                if constexpr (s + 1 < KS && s + 1 != KS1)
-                    af[(s + 1) & 1][mt] = afrag1(std::integral_constant<int, s + 1>{}, mt);
-                if constexpr (s + D < KS) {
-                    if (mt == 0) bring[s % D] = wfrag(s + D);
+    #pragma unroll
+            for (int mt = 0; mt < MWX; ++mt) {
+                const int R = (mg * MW + mt) * 32 + r;
+    #pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n0 = ng * 32 + 8 * gq + 4 * h;
+                    const float4 bb = bias2[gq];
+                    const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
+                                                fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
+                    *reinterpret_cast<uint2*>(otile + R * OPITCH + n0) = pk;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, af[s & 1][mt], acc[mt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
-        (step.template operator()<Ss>(), ...);
-    }(std::make_integer_sequence<int, KS>{});
-
-    RB_STAMP(5);
-    // ---- epilogue: out = ReLU(conv2 + projection + b2).  The accumulators go to a bf16 [pixel][COUT] tile in
-    // LDS (over the dead x image; rows padded by 16 B), then the workgroup copies the tile -- which is one
-    // contiguous run of NHWC output -- to global with 16-byte-per-lane coalesced stores. ----------------------
-    constexpr int OPITCH = COUT + 8;   // bf16 elements per LDS row
-    __syncthreads();                   // every wave is done reading the x / h images
-    bf16_t* otile = ximg;
-    if (active) {
-#pragma unroll
-        for (int mt = 0; mt < MW; ++mt) {
-            const int R = (mg * MW + mt) * 32 + r;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n0 = ng * 32 + 8 * gq + 4 * h;
-                const float4 bb = bias2[gq];
-                const uint2 pk = pack4_bf16(fmaxf(acc[mt][4 * gq] + bb.x, 0.f), fmaxf(acc[mt][4 * gq + 1] + bb.y, 0.f),
-                                            fmaxf(acc[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc[mt][4 * gq + 3] + bb.w, 0.f));
-                *reinterpret_cast<uint2*>(otile + R * OPITCH + n0) = pk;
-            }
-        }
-    }
+    if (MW > 1 && M - mg * MW * 32 <= (MW - 1) * 32) body.template operator()<(MW > 1 ? MW - 1 : 1)>();
+    else body.template operator()<MW>();
     __syncthreads();
     if (a.out != nullptr) {   // nullptr: the block output is only consumed by the fused head (pipeline: no parity tap)
         const int mvalid = (a.n_clips - clip0 < G ? a.n_clips - clip0 : G) * per;
