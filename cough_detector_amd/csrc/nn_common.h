@@ -38,7 +38,7 @@ template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return b
 template <int C>
 __device__ __forceinline__ int swz_off(int P, int j) {   // bf16 offset of 16-byte chunk j of pixel P
     constexpr int CH = C / 8, PPR = 16 / CH;             // chunks per pixel, pixels per 256-byte bank row
-    return P * C + 8 * (j ^ ((P / PPR) & (CH - 1)));
+    return P * C + 8 * (j ^ int((unsigned(P) / PPR) & (CH - 1)));   // P >= 0: unsigned division is one shift
 }
 
 }  // namespace

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
             constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
             if constexpr (c16 == 0) {                                // first k-step of a tap: new pixel
                 const int P = ((conv1 || proj) ? pr1[mt][kh] : pr2[mt][kh]) + kw;
-                ths[mt] = h ^ ((P / (16 / CH)) & (CH - 1));
+                ths[mt] = h ^ int((unsigned(P) / (16 / CH)) & (CH - 1));   // unsigned: a shift, not a signed division
                 tbase[mt] = ((conv1 || proj) ? ximg : himg) + P * C;
             }
             return *reinterpret_cast<const bf16x8*>(tbase[mt] + 8 * ((2 * c16) ^ ths[mt]));
