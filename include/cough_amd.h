@@ -43,9 +43,10 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------ featuriser (K1)
  * Replaces AudioPreprocessor.__init__ / extract_features / normalize
- * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for the shipped
- * flags (/root/reference/src/train.py:264-287).  Output row order as the reference
- * concatenates (:456-487): mel[0:n_mels], MFCC, delta, (delta-delta). */
+ * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for every flag of the
+ * constructor (the shipped set is /root/reference/src/train.py:264-287) at the STFT geometry
+ * given below.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
+ * (log-mel or PCEN), MFCC, delta, (delta-delta), (spectral contrast + centroid). */
 #define COUGH_MAX_CONTRAST_BANDS 16
 typedef struct cough_feat_config {
     int sample_rate;       /* 16000 */
