@@ -18,7 +18,7 @@ def test_state_dict_keys_match_reference(resnet_golden):
 def test_forward_matches_reference_goldens(resnet_golden):
     sd, vec = resnet_golden
     logits, (a1, a2, a3) = resnet.forward(vec["x"], sd, return_intermediates=True)
-    assert a1.shape == (12, 32, 22, 25) and a2.shape == (12, 64, 11, 13) and a3.shape == (12, 128, 6, 7)
+    assert a1.shape == (32, 32, 22, 25) and a2.shape == (32, 64, 11, 13) and a3.shape == (32, 128, 6, 7)
     for got, want in ((a1, vec["a1"]), (a2, vec["a2"]), (a3, vec["a3"]), (logits, vec["logits"])):
         assert (got - want).abs().max() < 2e-5
     preds, probs = resnet.predict(vec["x"], sd)
