@@ -32,7 +32,7 @@ BYTES_PER_CLIP_FUSED = 64000 + 35200    # featurise + bf16 stem fused: waveform 
 FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
 FLOP_PER_CLIP_NO_STEM = 35668480        # minus the stem's 32*45*51*49 MAC (it runs inside the featurise kernel)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
 
@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=4096, help="clips per rank per step")
-    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16"), choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--featurize-only", action="store_true", help="time K1 alone (BASELINE configs[1])")
     args = ap.parse_args()
@@ -170,7 +170,7 @@ def main():
     model.to(dev).eval()
     feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
     pipe = cda.CoughPipeline(pre, model)
-    fused = args.dtype == "bf16" and not args.featurize_only   # the stem runs inside the featurise kernel
+    fused = args.dtype in ("bf16", "bf16x3") and not args.featurize_only   # the stem runs inside the featurise kernel
     gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if dist else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]

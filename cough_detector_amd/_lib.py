@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.s
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1
 SPEC_MAGNITUDE, SPEC_FULL_WINDOW = 1, 2
-DTYPE_FP32, DTYPE_BF16, _DTYPE_DIRECT = 0, 1, 2
-DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT}
+DTYPE_FP32, DTYPE_BF16, _DTYPE_DIRECT, DTYPE_BF16X3 = 0, 1, 2, 3
+DTYPES = {"fp32": DTYPE_FP32, "bf16": DTYPE_BF16, "_direct": _DTYPE_DIRECT, "bf16x3": DTYPE_BF16X3}
 
 # every symbol include/cough_amd.h declares (tests check the library exports all of them)
 SYMBOLS = (

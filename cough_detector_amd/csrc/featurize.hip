@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include <hip/hip_bf16.h>
@@ -112,12 +113,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 // geometry of the fused stem for the 90x101 feature image (resnet.hip: stem_bf16_kernel / stem_lds)
 constexpr int ST_H = 90, ST_P1H = 22, ST_P1W = 25, ST_ROWS = 94, ST_PITCH = 106;   // image width = NFRAMES
 constexpr int ST_PER = ST_P1H * ST_P1W, ST_TILES = (ST_PER + 7) / 8;
-static_assert(size_t(ST_ROWS) * ST_PITCH * 2 <= LDS_MEL, "the bf16 feature image aliases the dB buffer");
+constexpr size_t ST_IMG = size_t(ST_ROWS) * ST_PITCH * 2;   // bytes of one bf16 image
+static_assert(ST_IMG <= LDS_MEL, "the bf16 feature image aliases the dB buffer");
+// split-bf16 stem: two images (hi, lo) at the end of the workgroup's LDS, over everything but the z-scored MFCC rows
+constexpr size_t ST_X3_OFF = LDS_TOTAL - 2 * ST_IMG;
+static_assert(ST_X3_OFF % 16 == 0 && ST_IMG % 4 == 0 && ST_X3_OFF >= size_t(NMF) * 4, "hi / lo images vs the MFCC buffer");
 
 // PRE_EMPH: pre-emphasis is a separate instantiation (it never costs the shipped path registers).
-// STEM: the classifier's bf16 stem (conv7x7 s2 + BN + ReLU + maxpool, model.py:227-232) runs at the end of
-// the kernel out of a bf16 copy of the feature image in LDS; `out` may then be nullptr.
-template <bool PRE_EMPH, bool STEM>
+// STEM: the classifier's stem (conv7x7 s2 + BN + ReLU + maxpool, model.py:227-232) runs at the end of the kernel on
+// the matrix cores out of a bf16 copy of the feature image in LDS; `out` may then be nullptr.  1: plain bf16 operands,
+// bf16 output; 2: split-bf16 (image and weights as hi + lo, hi*hi + lo*hi + hi*lo per k-step), f32 output.
+template <bool PRE_EMPH, int STEM>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
@@ -363,8 +369,15 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
     }
     __syncthreads();
-    uint16_t* img = reinterpret_cast<uint16_t*>(melbuf);   // STEM: bf16 feature image, row = f + 3, col = t + 3
-    if constexpr (STEM) {
+    // STEM: bf16 feature image(s), row = f + 3, col = t + 3
+    uint16_t* img = STEM == 2 ? reinterpret_cast<uint16_t*>(smem + ST_X3_OFF) : reinterpret_cast<uint16_t*>(melbuf);
+    uint16_t* img_lo = img + ST_ROWS * ST_PITCH;   // STEM == 2
+    auto put = [&](int idx, float v) {
+        const uint16_t hi = f2bf(v);
+        img[idx] = hi;
+        if constexpr (STEM == 2) img_lo[idx] = f2bf(v - __uint_as_float(uint32_t(hi) << 16));
+    };
+    if constexpr (STEM != 0) {
         // the floored dB values move to registers, then the dB buffer becomes the zero-bordered bf16 image
         float2 dv[(NMEL * NFRAMES / 2 + THREADS - 1) / THREADS];
 #pragma unroll
@@ -373,8 +386,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             dv[it] = i2 < NMEL * NFRAMES / 2 ? reinterpret_cast<const float2*>(melbuf)[i2] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        for (int i = tid; i < ST_ROWS * ST_PITCH / 8; i += THREADS) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
-        for (int i = (ST_ROWS * ST_PITCH / 8) * 8 + tid; i < ST_ROWS * ST_PITCH; i += THREADS) img[i] = 0;
+        constexpr int NIMG = STEM == 2 ? 2 : 1;     // x3: hi and lo images are adjacent
+        for (int i = tid; i < NIMG * ST_ROWS * ST_PITCH / 8; i += THREADS) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = (NIMG * ST_ROWS * ST_PITCH / 8) * 8 + tid; i < NIMG * ST_ROWS * ST_PITCH; i += THREADS) img[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS; ++it) {
@@ -382,8 +396,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             if (e < NMEL * NFRAMES) {
                 const int m0 = e / NFRAMES, t0 = e - m0 * NFRAMES;
                 const int m1 = t0 + 1 < NFRAMES ? m0 : m0 + 1, t1 = t0 + 1 < NFRAMES ? t0 + 1 : 0;
-                img[(m0 + 3) * ST_PITCH + t0 + 3] = f2bf(fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f));
-                img[(m1 + 3) * ST_PITCH + t1 + 3] = f2bf(fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f));
+                put((m0 + 3) * ST_PITCH + t0 + 3, fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f));
+                put((m1 + 3) * ST_PITCH + t1 + 3, fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f));
             }
         }
     }
@@ -398,9 +412,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             o_delta[item] = d;
         }
         if (delta_delta == 1) dl[item] = d;
-        if constexpr (STEM) {
-            img[(NMEL + c + 3) * ST_PITCH + t + 3] = f2bf(row[t]);
-            img[(NMEL + NMFCC + c + 3) * ST_PITCH + t + 3] = f2bf(d);
+        if constexpr (STEM != 0) {
+            put((NMEL + c + 3) * ST_PITCH + t + 3, row[t]);
+            put((NMEL + NMFCC + c + 3) * ST_PITCH + t + 3, d);
         }
     }
     K1_STAMP(6);
@@ -413,32 +427,50 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             o_dd[item] = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
         }
     }
-    if constexpr (STEM) {
+    if constexpr (STEM != 0) {
         // ---- K2 fused: conv7x7 s2 p3 (1->32) + BN + ReLU + maxpool2 on v_mfma_f32_32x32x16_bf16.  K is 8 kernel
         // rows x 8 taps (7 + a zero tap; row 8 all zero): MFMA step st, lane half h <-> kernel row 2*st+h,
         // 8 consecutive image pixels per lane = 4 aligned ds_read_b32.  GEMM rows are (pool window, dy, dx), so
-        // the 2x2 max is a max over 4 accumulator registers of one lane. ------------------------------------
+        // the 2x2 max is a max over 4 accumulator registers of one lane.  STEM == 2: three MFMAs per step
+        // (image_hi * w_hi + image_lo * w_hi + image_hi * w_lo), f32 output. ---------------------------------
         __syncthreads();
+        constexpr int NP = STEM == 2 ? 2 : 1;   // operand planes
         const int sr = lane & 31, sh = lane >> 5;
-        bf16x8 bw[4];
+        bf16x8 bw[NP][4];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) bw[st] = *reinterpret_cast<const bf16x8*>(stem.wfrag + ((st * 2 + sh) * 32 + sr) * 8);
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                bw[pl][st] = *reinterpret_cast<const bf16x8*>(stem.wfrag + pl * 2048 + ((st * 2 + sh) * 32 + sr) * 8);
         const float bn = stem.bias[sr];
         const int q = sr >> 2, dy = (sr >> 1) & 1, dx = sr & 1;
-        uint16_t* oa = stem.a1 + clip * (long long)ST_PER * 32;
+        using out_t = std::conditional_t<STEM == 2, float, uint16_t>;
+        out_t* oa = reinterpret_cast<out_t*>(stem.a1) + clip * (long long)ST_PER * 32;
         auto frag_base = [&](int tile) -> const uint32_t* {
             int P = tile * 8 + q;
             if (P >= ST_PER) P = ST_PER - 1;
             const int ph = P / ST_P1W, pw = P - ph * ST_P1W;
             return reinterpret_cast<const uint32_t*>(img + (2 * (2 * ph + dy) + sh) * ST_PITCH + 2 * (2 * pw + dx));
         };
-        auto load_frags = [&](const uint32_t* base, bf16x8 (&a)[4]) {
+        auto load_frags = [&](const uint32_t* base, bf16x8 (&a)[NP][4]) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const uint32_t* p = base + pl * (ST_ROWS * ST_PITCH / 2) + st * ST_PITCH;   // +2 image rows per step = ST_PITCH dwords
+                    union { uint32_t u[4]; bf16x8 v; } t;
+                    t.u[0] = p[0]; t.u[1] = p[1]; t.u[2] = p[2]; t.u[3] = p[3];
+                    a[pl][st] = t.v;
+                }
+        };
+        auto mma = [&](const bf16x8 (&a)[NP][4], f32x16& c) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const uint32_t* p = base + st * ST_PITCH;   // +2 image rows per step = ST_PITCH dwords
-                union { uint32_t u[4]; bf16x8 v; } t;
-                t.u[0] = p[0]; t.u[1] = p[1]; t.u[2] = p[2]; t.u[3] = p[3];
-                a[st] = t.v;
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][st], bw[0][st], c, 0, 0, 0);
+                if constexpr (STEM == 2) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][st], bw[0][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][st], bw[1][st], c, 0, 0, 0);
+                }
             }
         };
         auto epilogue = [&](int tile, const f32x16& acc2, bool guard) {
@@ -447,7 +479,10 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 const int Po = tile * 8 + 2 * g + sh;
                 float v = fmaxf(fmaxf(acc2[4 * g], acc2[4 * g + 1]), fmaxf(acc2[4 * g + 2], acc2[4 * g + 3])) + bn;
                 v = fmaxf(v, 0.f);
-                if (!guard || Po < ST_PER) oa[Po * 32 + sr] = f2bf(v);
+                if (!guard || Po < ST_PER) {
+                    if constexpr (STEM == 2) oa[Po * 32 + sr] = v;
+                    else oa[Po * 32 + sr] = f2bf(v);
+                }
             }
         };
         // ST_TILES = 69: every wave owns 17 full tiles (wave, wave+4, ..., wave+64), taken two at a time so one
@@ -455,30 +490,24 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         static_assert(ST_TILES == 17 * WAVES + 1, "stem tile split");
         for (int it = 0; it < 16; it += 2) {
             const int ta = wave + WAVES * it, tbb = ta + WAVES;
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[NP][4], fb[NP][4];
             load_frags(frag_base(ta), fa);
             load_frags(frag_base(tbb), fb);
             f32x16 ca = {0}, cb = {0};
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st], bw[st], ca, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st], bw[st], cb, 0, 0, 0);
-            }
+            mma(fa, ca);
+            mma(fb, cb);
             epilogue(ta, ca, false);
             epilogue(tbb, cb, false);
         }
         {
             const int ta = wave + WAVES * 16;               // 17th full tile
             const bool last = wave == 0;                    // wave 0 also takes the partial tile 68
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[NP][4], fb[NP][4];
             load_frags(frag_base(ta), fa);
             load_frags(frag_base(last ? ST_TILES - 1 : ta), fb);
             f32x16 ca = {0}, cb = {0};
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st], bw[st], ca, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st], bw[st], cb, 0, 0, 0);
-            }
+            mma(fa, ca);
+            mma(fb, cb);
             epilogue(ta, ca, false);
             if (last) epilogue(ST_TILES - 1, cb, true);
         }
@@ -617,15 +646,18 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
     const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
-    const StemFuse none{nullptr, nullptr, nullptr};
-    if (stem)
-        hipLaunchKernelGGL((featurize_kernel<false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+    const StemFuse none{nullptr, nullptr, nullptr, 0};
+    if (stem && stem->x3)
+        hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
+    else if (stem)
+        hipLaunchKernelGGL((featurize_kernel<false, 1>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
     else if (f->cfg.use_pre_emphasis)
-        hipLaunchKernelGGL((featurize_kernel<true, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+        hipLaunchKernelGGL((featurize_kernel<true, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
     else
-        hipLaunchKernelGGL((featurize_kernel<false, false>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+        hipLaunchKernelGGL((featurize_kernel<false, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
     COUGH_HIP_CHECK(hipGetLastError());
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)

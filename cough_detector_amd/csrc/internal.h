@@ -9,11 +9,13 @@ struct cough_resnet;
 
 namespace cough {
 
-// bf16 stem (K2) executed at the end of the featurise kernel: the 90x101 feature image never leaves the CU.
+// Stem (K2) executed at the end of the featurise kernel: the 90x101 feature image never leaves the CU.
 struct StemFuse {
-    const uint16_t* wfrag;   // [4 steps][2 halves][32 channels][8 taps] MFMA fragments (resnet.hip)
+    const uint16_t* wfrag;   // [4 steps][2 halves][32 channels][8 taps] bf16 MFMA fragments (resnet.hip); x3: the lo
+                             // fragments follow the hi ones
     const float* bias;       // [32]
-    uint16_t* a1;            // [n][22][25][32] bf16 NHWC
+    void* a1;                // [n][22][25][32] NHWC: bf16 (x3 == 0) or f32 (x3 == 1)
+    int x3;                  // 1: split-bf16 operands (feature image and weights as hi + lo, three MFMAs per k-step)
 };
 
 // featurize.hip: d_feat may be nullptr when `stem` is given (features not materialised)

@@ -24,12 +24,14 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
 #include "internal.h"
 #include "nn_common.h"
 #include "conv_gemm.h"
+#include "resblock_x3.h"
 
 #define COUGH_DTYPE_DIRECT 2
 
@@ -125,12 +127,23 @@ inline StemLds stem_lds(const Shapes& s) {
     return l;
 }
 
+// X3: split-bf16 operands -- the image and the weights as hi + lo bf16 pairs, three MFMAs per step
+// (image_hi * w_hi + image_lo * w_hi + image_hi * w_lo, the order of the fused stem in featurize.hip), f32 output.
+template <bool X3>
 __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w,
                                                         int nrows, int pitch,
-                                                        const bf16_t* __restrict__ wfrag /* [4][2][32][8] */,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out) {
+                                                        const bf16_t* __restrict__ wfrag /* [X3 ? 2 : 1][4][2][32][8] */,
+                                                        const float* __restrict__ bias,
+                                                        std::conditional_t<X3, float, bf16_t>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);
+    constexpr int NP = X3 ? 2 : 1;
+    const int plane = nrows * pitch;   // elements of one image (even: pitch is even); the lo image follows the hi one
+    auto put = [&](int idx, float v) {
+        const bf16_t hi = f2bf(v);
+        img[idx] = hi;
+        if constexpr (X3) img[plane + idx] = f2bf(v - bf2f(hi));
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const long long clip = blockIdx.x;
     const float* src = feat + clip * (long long)H * W;
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
             else { pv[u].x = src[2 * p]; if (2 * p + 1 < H * W) pv[u].y = src[2 * p + 1]; }
         }
     }
-    for (int i = tid; i < nrows * pitch / 8; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = (nrows * pitch / 8) * 8 + tid; i < nrows * pitch; i += 256) img[i] = 0;
+    for (int i = tid; i < NP * plane / 8; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = (NP * plane / 8) * 8 + tid; i < NP * plane; i += 256) img[i] = 0;
     __syncthreads();
     const float inv_w = 1.0f / float(W);
 #pragma unroll
@@ -159,22 +172,25 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
         const int e = 2 * (tid + u * 256);
         if (e < H * W) {
             const int ih = fdiv(e, W, inv_w), iw = e - ih * W;
-            img[(ih + 3) * pitch + iw + 3] = f2bf(pv[u].x);
+            put((ih + 3) * pitch + iw + 3, pv[u].x);
             if (e + 1 < H * W) {
                 const int ih1 = iw + 1 < W ? ih : ih + 1, iw1 = iw + 1 < W ? iw + 1 : 0;
-                img[(ih1 + 3) * pitch + iw1 + 3] = f2bf(pv[u].y);
+                put((ih1 + 3) * pitch + iw1 + 3, pv[u].y);
             }
         }
     }
-    bf16x8 bw[4];
+    bf16x8 bw[NP][4];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) bw[st] = *reinterpret_cast<const bf16x8*>(wfrag + ((st * 2 + h) * 32 + r) * 8);
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            bw[pl][st] = *reinterpret_cast<const bf16x8*>(wfrag + pl * 2048 + ((st * 2 + h) * 32 + r) * 8);
     const float bn = bias[r];
     __syncthreads();
 
     const int per_clip = P1h * P1w, n_tiles = (per_clip + 7) / 8;
     const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
-    bf16_t* o = out + clip * (long long)per_clip * STEM_N;
+    auto* o = out + clip * (long long)per_clip * STEM_N;
     for (int tile = wave; tile < n_tiles; tile += 4) {
         int P = tile * 8 + q;
         if (P >= per_clip) P = per_clip - 1;
@@ -187,14 +203,24 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
             const uint32_t* p = base + st * pitch;   // +2 image rows per step = 2*pitch bf16 = pitch dwords
             union { uint32_t u[4]; bf16x8 v; } a;
             a.u[0] = p[0]; a.u[1] = p[1]; a.u[2] = p[2]; a.u[3] = p[3];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[st], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[0][st], acc, 0, 0, 0);
+            if constexpr (X3) {
+                const uint32_t* pl = p + plane / 2;
+                union { uint32_t u[4]; bf16x8 v; } al;
+                al.u[0] = pl[0]; al.u[1] = pl[1]; al.u[2] = pl[2]; al.u[3] = pl[3];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bw[0][st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bw[1][st], acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int Po = tile * 8 + 2 * g + h;
             float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bn;
             v = fmaxf(v, 0.f);
-            if (Po < per_clip) o[Po * STEM_N + r] = f2bf(v);
+            if (Po < per_clip) {
+                if constexpr (X3) o[Po * STEM_N + r] = v;
+                else o[Po * STEM_N + r] = f2bf(v);
+            }
         }
     }
 }
@@ -771,6 +797,7 @@ struct cough_resnet {
     float* d_stem_b;       // [32]
     void* d_w[4];          // packed [N][Ktot]: b0.conv1, b0.conv2+skip, b1.conv1, b1.conv2+skip
     cough::bf16_t* d_wfrag[4];   // bf16 mode: the same weights as MFMA fragments [K/16][N/32][64][8] (fused block kernels)
+    cough::bf16_t* d_wx3[2];     // bf16x3 mode: split-bf16 fragments of block i (conv1, projection, conv2; resblock_x3.h)
     float* d_b[4];
     int ktot[4];
     float* d_fcw;          // [2][128]
@@ -785,6 +812,12 @@ int upload(void** dst, const std::vector<T>& v) {
     COUGH_HIP_CHECK(hipMalloc(dst, v.size() * sizeof(T)));
     COUGH_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return COUGH_OK;
+}
+
+int upload_x3(cough_resnet* m, int blk, const FoldedConv& c1, const FoldedConv& c2, const FoldedConv& sk) {
+    std::vector<bf16_t> wf;
+    pack_x3_fragments(wf, c1.w, 9 * c1.C, sk.w, sk.C, c2.w, 9 * c2.C, c1.N);
+    return upload(reinterpret_cast<void**>(&m->d_wx3[blk]), wf);
 }
 
 int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const FoldedConv* skip) {
@@ -869,8 +902,14 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
-            hipLaunchKernelGGL(stem_bf16_kernel, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w, l.nrows,
-                               l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1));
+            hipLaunchKernelGGL(stem_bf16_kernel<false>, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
+                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1));
+        }
+    } else if (m->dtype == COUGH_DTYPE_BF16X3 && 2 * stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
+        if constexpr (sizeof(T) == 4) {
+            const StemLds l = stem_lds(s);
+            hipLaunchKernelGGL(stem_bf16_kernel<true>, dim3(n), dim3(256), 2 * l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
+                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<float*>(w.a1));
         }
     } else {
         const long long tiles = (n_pool + 7) / 8;
@@ -887,6 +926,30 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     bool head_done = false;   // the fused block-1 kernel also runs the head
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
+        if constexpr (sizeof(T) == 4) {   // bf16x3: fused split-bf16 block kernels for the shipped 90x101 feature image
+            if (m->dtype == COUGH_DTYPE_BF16X3 && ((i == 0 && k.xh == 22 && k.xw == 25) || (i == 1 && k.xh == 11 && k.xw == 13))) {
+                RbxArgs ra{};
+                ra.x = reinterpret_cast<const float*>(k.x);
+                ra.n_clips = n;
+                ra.wf = m->d_wx3[i];
+                ra.b1 = m->d_b[k.s1];
+                ra.b2 = m->d_b[k.s2];
+                ra.out = reinterpret_cast<float*>(k.out);
+                if (i == 0) {
+                    using Cfg = RbxCfg<32, 64, 1, 22, 25>;
+                    hipLaunchKernelGGL((resblock_x3_kernel<32, 64, 1, 22, 25>), dim3(n), dim3(Cfg::THREADS), Cfg::LDS, st, ra);
+                } else {
+                    using Cfg = RbxCfg<64, 128, 2, 11, 13>;
+                    ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds;
+                    if (stem_done) ra.out = nullptr;   // pipeline: nobody reads a3
+                    hipLaunchKernelGGL((resblock_x3_kernel<64, 128, 2, 11, 13>), dim3((n + 1) / 2), dim3(Cfg::THREADS), Cfg::LDS,
+                                       st, ra);
+                    head_done = true;
+                }
+                COUGH_HIP_CHECK(hipGetLastError());
+                continue;
+            }
+        }
         if constexpr (sizeof(T) == 2) {   // bf16: fused block kernel when the clip group fits one workgroup's LDS
             using Cfg0 = RbCfg<32, 64, 1, 3, 4>;     // block 0: 1 clip (66 KB LDS: two workgroups per CU), 4 waves = 2 tile groups x 2 channel tiles
             using Cfg1 = RbCfg<64, 128, 3, 2, 8>;    // block 1: 3 clips, 8 waves = 2 pixel-tile pairs x 4 channel tiles (2 waves per SIMD)
@@ -956,7 +1019,8 @@ extern "C" int cough_debug_set_rb_stamp_buffer(void* d_buf) {
 extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype) {
     using namespace cough;
     COUGH_REQUIRE(out && w, COUGH_EINVAL, "cough_resnet_create: NULL argument");
-    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_DIRECT, COUGH_EINVAL,
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_DIRECT ||
+                      dtype == COUGH_DTYPE_BF16X3, COUGH_EINVAL,
                   "cough_resnet_create: unknown dtype %d", dtype);
     const cough_conv_bn* all[7] = {&w->stem, &w->block[0].conv1, &w->block[0].conv2, &w->block[0].skip,
                                    &w->block[1].conv1, &w->block[1].conv2, &w->block[1].skip};
@@ -979,14 +1043,24 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
             for (int k = 0; k < 49; ++k) wk[size_t(k) * 32 + n] = f.w[size_t(n) * 49 + k];
         err = upload(reinterpret_cast<void**>(&m->d_stem_w), wk);
         if (!err) err = upload(reinterpret_cast<void**>(&m->d_stem_b), f.b);
-        if (!err && dtype == COUGH_DTYPE_BF16) {   // B fragments of stem_bf16_kernel: k = 16*st + 8*h + jj <-> (kh = 2*st+h, kw = jj)
-            std::vector<bf16_t> wf(size_t(4) * 2 * 32 * 8, 0);
+        if (!err && (dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_BF16X3)) {
+            // B fragments of stem_bf16_kernel: k = 16*st + 8*h + jj <-> (kh = 2*st+h, kw = jj); the lo fragments
+            // (bf16 of the rounding residual, used by the split-bf16 stem) follow the hi ones
+            std::vector<bf16_t> wf(size_t(2) * 4 * 2 * 32 * 8, 0);
             for (int st = 0; st < 4; ++st)
                 for (int hh = 0; hh < 2; ++hh)
                     for (int n = 0; n < 32; ++n)
                         for (int jj = 0; jj < 7; ++jj) {
                             const int kh = 2 * st + hh;
-                            if (kh < 7) wf[((size_t(st) * 2 + hh) * 32 + n) * 8 + jj] = f2bf_host(f.w[size_t(n) * 49 + kh * 7 + jj]);
+                            if (kh >= 7) continue;
+                            const float v = f.w[size_t(n) * 49 + kh * 7 + jj];
+                            const bf16_t hi = f2bf_host(v);
+                            const uint32_t hb = uint32_t(hi) << 16;
+                            float hf;
+                            std::memcpy(&hf, &hb, 4);
+                            const size_t idx = ((size_t(st) * 2 + hh) * 32 + n) * 8 + jj;
+                            wf[idx] = hi;
+                            wf[2048 + idx] = f2bf_host(v - hf);
                         }
             err = upload(reinterpret_cast<void**>(&m->d_stem_wfrag), wf);
         }
@@ -998,6 +1072,7 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         const FoldedConv sk = fold(w->block[i].skip, cout[i], cin[i], 1, 1, eps);
         err = upload_packed(m, 2 * i, c1, nullptr);
         if (!err) err = upload_packed(m, 2 * i + 1, c2, &sk);
+        if (!err && dtype == COUGH_DTYPE_BF16X3) err = upload_x3(m, i, c1, c2, sk);
     }
     if (!err) {
         std::vector<float> fw(w->fc_w, w->fc_w + 256), fb(w->fc_b, w->fc_b + 2);
@@ -1012,6 +1087,17 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         hipError_t e = hipSuccess;
         for (const void* fn : fused)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("cough_resnet_create: %s", hipGetErrorString(e));
+            err = COUGH_EHIP;
+        }
+    }
+    if (!err && dtype == COUGH_DTYPE_BF16X3) {   // more than 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, 2, 11, 13>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("cough_resnet_create: %s", hipGetErrorString(e));
             err = COUGH_EHIP;
@@ -1035,6 +1121,8 @@ extern "C" void cough_resnet_destroy(cough_resnet* m) {
         (void)hipFree(m->d_w[i]);
         (void)hipFree(m->d_b[i]);
     }
+    (void)hipFree(m->d_wx3[0]);
+    (void)hipFree(m->d_wx3[1]);
     (void)hipFree(m->d_fcw);
     (void)hipFree(m->d_fcb);
     delete m;
@@ -1094,7 +1182,8 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
 namespace cough {
 namespace {
 bool can_fuse_stem(const cough_featurizer* f, const cough_resnet* m) {
-    return m->dtype == COUGH_DTYPE_BF16 && featurizer_stem_fusable(f) && cough_featurizer_num_frames(f) == 101;
+    return (m->dtype == COUGH_DTYPE_BF16 || m->dtype == COUGH_DTYPE_BF16X3) && featurizer_stem_fusable(f) &&
+           cough_featurizer_num_frames(f) == 101;
 }
 }  // namespace
 }  // namespace cough
@@ -1127,9 +1216,10 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
     if (ev_featurize_begin) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_begin), st));
     if (can_fuse_stem(f, m)) {
         const Workspace w = carve(m, ws, n_clips, s);
-        const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<uint16_t*>(w.a1)};
+        const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, w.a1, m->dtype == COUGH_DTYPE_BF16X3 ? 1 : 0};
         if (int e = launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st)) return e;
         if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
+        if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
         return forward_impl<bf16_t>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
     }
     const size_t net_bytes = cough_resnet_workspace_bytes(m, n_clips, H, W);

@@ -135,7 +135,11 @@ typedef struct cough_resnet_weights {
 } cough_resnet_weights;
 
 #define COUGH_DTYPE_FP32 0 /* exact-f32 MFMA (v_mfma_f32_*_f32): CPU-reference numerics */
-#define COUGH_DTYPE_BF16 1 /* bf16 operands and activations, f32 accumulate */
+#define COUGH_DTYPE_BF16 1 /* bf16 operands and activations, f32 accumulate: FAST, APPROXIMATE (logit error ~2e-2 of the
+                              class-margin spread; outside the 1e-3 parity tolerance for a trained head) */
+#define COUGH_DTYPE_BF16X3 3 /* split-bf16: every operand as hi + lo bf16 (16 significant bits), three MFMAs per k-step
+                                (hi*hi + hi*lo + lo*hi), f32 accumulate, f32 activations in HBM: logits within 1e-3 of
+                                the f32 reference at a trained head's scale.  cough_resnet_create only */
 
 typedef struct cough_resnet cough_resnet;
 

@@ -7,7 +7,7 @@ import torch
 import cough_detector_amd as cda
 from cough_detector_amd import synth
 from oracle import cnn as ocnn, featurizer as ofeat, resnet as ores
-from parity import FEAT_TOL, LOGIT_TOL, SHIPPED, feature_errors, synth_batch
+from parity import FEAT_TOL, LOGIT_TOL, SHIPPED, feature_errors, realistic_state_dict, synth_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -28,12 +28,13 @@ def test_featuriser_random_batches_and_strides():
         assert mel < FEAT_TOL and rel < FEAT_TOL, (b, stride, mel, rel)
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", LOGIT_TOL)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16x3", LOGIT_TOL)])
 def test_residual_net_random_image_sizes(dtype, tol):
-    """The classifier is fully convolutional: other (F, T) sizes take the unfused kernels (bf16) or the same f32
-    kernels with other shapes."""
+    """The classifier is fully convolutional: other (F, T) sizes take the same f32 kernels with other shapes (the
+    split-bf16 kernels are compiled for the shipped 90x101 image; a bf16x3 model runs other sizes on the exact-f32
+    kernels).  Trained-scale head."""
     rng = np.random.default_rng(5)
-    sd = synth.random_state_dict(seed=9)
+    sd = realistic_state_dict(9)
     m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
     m.load_state_dict(sd)
     m.cuda()
@@ -59,14 +60,14 @@ def test_conv_stack_random_image_sizes(cnn_golden, kind):
 
 
 def test_pipeline_every_small_batch_size():
-    """Batches that are not multiples of the block kernels' clip groups (1 and 3 clips per workgroup), of the STFT's
+    """Batches that are not multiples of the block kernels' clip groups (1, 2 or 3 clips per workgroup), of the STFT's
     8-clip slabs, or of anything else: fused pipeline == featurise -> classify, and both within tolerance of the
     oracle."""
-    sd = synth.random_state_dict(seed=4)
+    sd = realistic_state_dict(4)
     pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
     wav = synth_batch(2000, 23)
     ref = ores.forward(ofeat.extract_features_batch(wav, normalize_first=True)[:, None], sd)
-    for dtype, tol in (("bf16", LOGIT_TOL), ("fp32", 1e-4)):
+    for dtype, tol in (("bf16x3", LOGIT_TOL), ("bf16", 0.2), ("fp32", 1e-4)):   # "bf16": approximate mode, ~2 % of the spread
         m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
         m.load_state_dict(sd)
         m.cuda()

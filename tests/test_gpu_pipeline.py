@@ -10,7 +10,7 @@ from parity import FEAT_TOL, LOGIT_TOL, SHIPPED, feature_errors, synth_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "fp32"])
 @pytest.mark.parametrize("normalize", [True, False])
 def test_pipeline_equals_two_step(resnet_golden, dtype, normalize):
     sd, _ = resnet_golden
@@ -38,7 +38,7 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
     B = 4096
     w = synth_batch(9000, B, peak_normalize=False)
     pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
-    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
     model.load_state_dict(sd)
     pipe = cda.CoughPipeline(pre, model.cuda())
     logits = pipe(w.cuda(), normalize=True)
@@ -46,8 +46,10 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
     sample = torch.arange(0, B, 32)
     ref = ores.forward(ofeat.extract_features_batch(w[sample], normalize_first=True).unsqueeze(1), sd)
     err = (logits[sample].cpu() - ref).abs().max().item()
-    print(f"pipeline bf16 B=4096 sample: logits max abs err {err:.2e}")
+    print(f"pipeline bf16x3 B=4096 sample: logits max abs err {err:.2e}")
     assert err < LOGIT_TOL
+    keep = (ref[:, 1] - ref[:, 0]).abs() > 2 * LOGIT_TOL
+    assert torch.equal(logits[sample].cpu().argmax(1)[keep], ref.argmax(1)[keep]) and keep.float().mean() > 0.98
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record(); ev[1].record()
     pipe(w.cuda(), events=ev)

@@ -16,29 +16,43 @@ def make_model(sd, dtype):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "_direct", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "_direct", "bf16x3"])
 def test_reference_goldens(resnet_golden, dtype):
+    """Reference-generated goldens with a trained-scale head (class-margin std 2.5, |logit| up to 3.9): logits within
+    1e-3 abs and argmax exact on EVERY clip -- no margin mask -- for the exact-f32 kernels and for the split-bf16
+    ("bf16x3") kernels the benchmark runs."""
     sd, vec = resnet_golden
     m = make_model(sd, dtype)
     logits = m(vec["x"].cuda())
-    act_tol = 2e-5 if dtype != "bf16" else 3e-2
     for which, key in ((1, "a1"), (2, "a2"), (3, "a3")):
         got = m.read_activation(which).cpu()
         assert got.shape == vec[key].shape
         err = (got - vec[key]).abs().max().item()
         print(f"{dtype} {key}: max abs err {err:.2e} (ref max {vec[key].abs().max():.2f})")
-        assert err < act_tol * max(1.0, vec[key].abs().max().item())
+        assert err < 2e-5 * max(1.0, vec[key].abs().max().item())
     err = (logits.cpu() - vec["logits"]).abs().max().item()
     print(f"{dtype} logits: max abs err {err:.2e}")
-    assert err < (LOGIT_TOL if dtype == "bf16" else 5e-6)
+    assert err < (LOGIT_TOL if dtype == "bf16x3" else 1e-4)
     preds, probs = m.predict(vec["x"].cuda())
     assert (probs.cpu() - vec["probs"]).abs().max() < LOGIT_TOL
-    if dtype != "bf16":      # golden class margins go down to 9e-4: exact only for the f32 paths
-        assert torch.equal(preds.cpu(), vec["preds"])
-    else:
-        margin = (vec["logits"][:, 1] - vec["logits"][:, 0]).abs()
-        keep = margin > 2 * LOGIT_TOL
-        assert torch.equal(preds.cpu()[keep], vec["preds"][keep])
+    assert torch.equal(preds.cpu(), vec["preds"])
+
+
+def test_plain_bf16_is_approximate(resnet_golden):
+    """compute_dtype="bf16" (single bf16 operands and activations) is the fast APPROXIMATE mode: on the trained-scale
+    goldens its logit error is ~2 % of the class-margin spread (5.5e-2 measured), far outside LOGIT_TOL, so it is NOT
+    what the headline runs.  This pins the size of that error (it must stay a few percent of the margin spread) and
+    that classes agree wherever the reference margin exceeds twice the error."""
+    sd, vec = resnet_golden
+    m = make_model(sd, "bf16")
+    logits = m(vec["x"].cuda()).cpu()
+    err = (logits - vec["logits"]).abs().max().item()
+    spread = (vec["logits"][:, 1] - vec["logits"][:, 0]).std().item()
+    print(f"bf16 logits: max abs err {err:.2e} = {100 * err / spread:.1f} % of the margin spread")
+    assert LOGIT_TOL < err < 0.05 * spread
+    margin = (vec["logits"][:, 1] - vec["logits"][:, 0]).abs()
+    keep = margin > 2 * err
+    assert torch.equal(logits.argmax(1)[keep], vec["preds"][keep]) and keep.float().mean() > 0.8
 
 
 def test_single_window_batch1_like_reference_engine(resnet_golden):
@@ -73,7 +87,7 @@ def test_weights_reload_rebuilds_native_handle():
         assert (m(x.cuda()).cpu() - ores.forward(x, sd)).abs().max() < 5e-5
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 def test_full_size_batch(resnet_golden, dtype):
     """BASELINE configs[2]: B = 4096 end-to-end features + classifier; logits 1e-3 abs, argmax exact."""
     sd, _ = resnet_golden
@@ -97,10 +111,12 @@ def test_full_size_batch(resnet_golden, dtype):
     err = (logits[sample].cpu() - ref_logits).abs()
     print(f"{dtype} B=4096 sample of {len(sample)}: logits max abs err {err.max():.2e}")
     assert err.max() < LOGIT_TOL
+    # argmax: exact wherever the reference margin exceeds the tolerance itself (both classes of a tie-within-tolerance
+    # clip are "within 1e-3"); with a margin spread of ~2.5 that is every clip but a handful
     margin = (ref_logits[:, 1] - ref_logits[:, 0]).abs()
-    keep = margin > (2 * err.max() if dtype == "bf16" else 1e-5)
+    keep = margin > 2 * LOGIT_TOL
     assert torch.equal(logits[sample].cpu().argmax(1)[keep], ref_logits.argmax(1)[keep])
-    assert keep.float().mean() > 0.9
+    assert keep.float().mean() > 0.98
 
 
 def test_empty_batch(resnet_golden):
