@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: 1 s @ 16 kHz clips/s through featurise (K1) + CoughDetectorResidual (K2-K5).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over one batch of B = 4096 synthetic clips that are already
-resident in HBM (BASELINE.json configs[2]).  With N ranks the clip stream is sharded round-robin
-(clip i -> rank i mod N, weak scaling: every rank runs B clips per step) and the only exchange is
-an RCCL all-gather of the (B, 2) logits per step.  Rank 0 prints ONE JSON line.
+With N > 1 and no torchrun environment this process only LAUNCHES the ranks (``python -m torch.distributed.run
+--nproc-per-node N bench.py ...`` as a child, before anything touches the GPU), relays rank 0's single JSON line
+and exits with the children's status; started under torchrun (WORLD_SIZE set) it is one of the ranks.
 
-Extra objects on that line: ``roofline`` (featurise kernel vs HBM: algorithmic 100 360 B/clip over
-the kernel's HIP-event time inside the timed region), ``roofline_classifier`` (42.87 MFLOP/clip vs
-the dense MFMA peak of the compute dtype) and ``cpu_baseline`` (the torch-CPU oracle timed on this
-box's host cores on a bounded sample; rank 0, N = 1 only).
+A step is one pass of the hot path over one batch of B = 4096 synthetic clips that are already resident in HBM
+(BASELINE.json configs[2]).  The clips are generated ON THE DEVICE from their global index (``cough_synth_clips``) and
+the steps rotate over ``--rotate`` distinct batches (default 3 x 262 MB > 2 x the 256 MiB Infinity Cache), so every
+step's waveform read comes from HBM.  With N ranks the clip stream is sharded round-robin (clip i -> rank i mod N,
+weak scaling: every rank runs B clips per step) and the only exchange is an RCCL all-gather of the (B, 2) logits per
+step.  ``--total-clips T`` runs configs[3] as worded: a T-clip stream (default use: 1 000 000), every clip distinct,
+sharded round-robin and resident in HBM (64 KB per clip), one pass.  Rank 0 prints ONE JSON line.
+
+Before ``--warmup`` an untimed pre-warm (``--prewarm-s``, default 0.6 s of the same pipeline, reported as
+``prewarm_s``) brings the GPU to its sustained clocks, so a short timed region (the driver's 20 steps = 14 ms) reads
+the same as a long one.
+
+Extra objects on that line: ``roofline`` (featurise kernel vs HBM: algorithmic bytes per clip over the kernel's
+HIP-event time inside the timed region), ``roofline_classifier`` (algorithmic 35.67 MFLOP/clip of the residual blocks
+vs the dense bf16 MFMA peak; the split-bf16 scheme issues 3 MFMAs per algorithmic one, reported as ``mfma_issue_frac``),
+``roofline_stft`` (the STFT stage on its own) and ``cpu_baseline`` (the torch-CPU oracle timed on this box's host
+cores on a bounded sample; rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,19 +42,30 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_CLIP = 64000 + 36360          # featurise: waveform read + (90,101) f32 written
 BYTES_PER_CLIP_STFT = 64000 + 103828    # STFT stage alone: waveform read + (257,101) f32 power written
-BYTES_PER_CLIP_FUSED = 64000 + 35200    # featurise + bf16 stem fused: waveform read + (22,25,32) bf16 written
+# featurise + stem fused: waveform read + the stem's (22,25,32) output written -- bf16 (plain bf16) or f32 (bf16x3)
+BYTES_PER_CLIP_FUSED = {"bf16": 64000 + 35200, "bf16x3": 64000 + 70400}
 FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
 FLOP_PER_CLIP_NO_STEM = 35668480        # minus the stem's 32*45*51*49 MAC (it runs inside the featurise kernel)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+MFMA_PER_PRODUCT = {"bf16": 1, "bf16x3": 3, "fp32": 1}
+DTYPE_LABEL = {
+    "bf16x3": "bf16x3: split-bf16 MFMA (feature image, activations and BN-folded weights as hi+lo bf16 pairs, 3 "
+              "v_mfma_f32_32x32x16_bf16 per k-step, f32 accumulate, f32 activations in HBM); featuriser f32",
+    "bf16": "bf16 (approximate mode): single-bf16 MFMA operands incl. the stem's feature image, bf16 activations, "
+            "f32 accumulate; featuriser f32",
+    "fp32": "f32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); featuriser f32",
+}
 SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
 
-def measured_traffic(batch: int, fused: bool = False):
+def measured_traffic(batch: int, variant: str):
     """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (tools/pmc_k1.sh ->
     tools/pmc_to_json.py; FETCH_SIZE doubled per the gfx950 calibration).  PMC cannot be collected from
-    inside this process, so the figure is read from profiles/ and only used when the batch matches."""
-    path = os.path.join(ROOT, "profiles", "r01_k1_fused_pmc.json" if fused else "r01_k1_pmc.json")
+    inside this process, so the figure is read from profiles/ and only used when the batch matches.
+    ``variant``: "k1" (featurise alone), "k1_fused_bf16" or "k1_fused_bf16x3"."""
+    path = os.path.join(ROOT, "profiles", {"k1": "r01_k1_pmc.json", "k1_fused_bf16": "r01_k1_fused_pmc.json",
+                                           "k1_fused_bf16x3": "r02_k1_fused_x3_pmc.json"}[variant])
     try:
         with open(path) as f:
             p = json.load(f)
@@ -51,20 +76,20 @@ def measured_traffic(batch: int, fused: bool = False):
     return None, None
 
 
-def stft_stage(pre, wav, launches: int = 200) -> dict:
+def stft_stage(pre, batches, launches: int = 210) -> dict:
     """The STFT stage on its own (cough_spectrogram = the reference's T.Spectrogram, preprocessing.py:131-136):
     waveform in, 257x101 power spectrogram out, timed with HIP events on the launch stream.  Reported beside the
     headline because BASELINE.json quotes an HBM fraction "for the STFT stage"; the fused featuriser above never
     writes this tensor."""
     import torch
-    b = wav.shape[0]
-    spec = torch.empty((b, 257, 101), dtype=torch.float32, device=wav.device)
-    for _ in range(50):
-        pre.spectrogram_batch(wav, out=spec)
+    b = batches[0].shape[0]
+    spec = torch.empty((b, 257, 101), dtype=torch.float32, device=batches[0].device)
+    for i in range(60):
+        pre.spectrogram_batch(batches[i % len(batches)], out=spec)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(launches):
-        pre.spectrogram_batch(wav, out=spec)
+    for i in range(launches):                      # inputs rotate over distinct batches: every read comes from HBM
+        pre.spectrogram_batch(batches[i % len(batches)], out=spec)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / launches
@@ -123,31 +148,70 @@ def cpu_baseline(budget_s: float) -> dict:
             "batched_sample": f"{m} clips at batch 256, single STFT, {default_threads} threads"}
 
 
-def main():
+def build_launch_cmd(argv, n_ranks: int, port: int):
+    """The child command a ``--gpus N`` parent runs: torchrun's module entry with one rank per GPU of this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args, argv) -> int:
+    """Parent of a multi-rank run: no GPU call is made here (device_count() does not initialise the runtime)."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py --gpus {args.gpus}: only {have} device(s) visible on this node "
+              f"(ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES?)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    proc = subprocess.run(build_launch_cmd(argv, args.gpus, port), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)                     # anything else the ranks wrote to stdout
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if lines else 1
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults long enough for the GPU to reach its sustained clocks (a 25 ms run reads ~12 % low); still < 2 s of GPU time
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4096, help="clips per rank per step")
-    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16"), choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16x3"), choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--featurize-only", action="store_true", help="time K1 alone (BASELINE configs[1])")
-    args = ap.parse_args()
+    ap.add_argument("--rotate", type=int, default=3, help="distinct device-resident input batches the steps cycle over")
+    ap.add_argument("--prewarm-s", type=float, default=0.6, help="untimed GPU pre-warm before --warmup (seconds)")
+    ap.add_argument("--total-clips", type=int, default=0,
+                    help="configs[3]: one pass over a stream of this many distinct clips (all ranks together); "
+                         "overrides --steps and --rotate")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    force_dist = os.environ.get("COUGH_BENCH_FORCE_DIST") == "1"   # rehearse the multi-rank path with one rank
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     from cough_detector_amd.hostcpu import bound_torch_threads
     bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("COUGH_BENCH_FORCE_DIST") == "1":   # the env switch rehearses the path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL writes its version banner and warnings to stdout (at the first collective); stdout must carry exactly
@@ -159,11 +223,27 @@ def main():
 
     import cough_detector_amd as cda
     from cough_detector_amd import synth
-    from cough_detector_amd.distributed import gather_logits_finish, gather_logits_start
+    from cough_detector_amd.distributed import gather_logits_finish, gather_logits_start, local_count
 
-    B, K, W = args.batch, args.steps, args.warmup
-    # rank r owns global clips r, r+N, r+2N, ... (round-robin); synthetic, regenerated from the clip index
-    wav = torch.from_numpy(synth.make_clips(rank, B, stride=world, peak_normalize=False)).to(dev)
+    B, W = args.batch, args.warmup
+    # rank r owns global clips r, r+N, r+2N, ... (round-robin); clip g is generated on the device from seed g
+    if args.total_clips > 0:
+        n_local = local_count(args.total_clips, rank, world)
+        K = (local_count(args.total_clips, 0, world) + B - 1) // B          # steps of the rank with the most clips
+        pool = torch.empty((max(n_local, 1), 16000), dtype=torch.float32, device=dev)
+        for j in range(0, n_local, B):
+            c = min(B, n_local - j)
+            synth.device_clips(rank + j * world, c, seed_stride=world, out=pool[j:j + c])
+        batches = [pool[j * B:min((j + 1) * B, n_local)] for j in range(K)]
+        step_total = [min(args.total_clips, (j + 1) * B * world) - j * B * world for j in range(K)]
+    else:
+        K, n_local = args.steps, None
+        R = max(1, args.rotate)
+        pool = torch.empty((R * B, 16000), dtype=torch.float32, device=dev)
+        for j in range(R):
+            synth.device_clips(rank + j * B * world, B, seed_stride=world, out=pool[j * B:(j + 1) * B])
+        batches = [pool[(j % R) * B:(j % R + 1) * B] for j in range(K)]
+        step_total = [B * world] * K
     pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
     model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=args.dtype)
     model.load_state_dict(synth.random_state_dict(seed=3))
@@ -180,10 +260,11 @@ def main():
             e.record()
 
     def step(i, timed):
+        wav = batches[i % K]          # may be empty on the last step of a ragged --total-clips stream (still gathers)
         if args.featurize_only:
             if timed:
                 ev[i][0].record()
-            pre.featurize_batch(wav, normalize=True, out=feats)
+            pre.featurize_batch(wav, normalize=True, out=feats[:wav.shape[0]])
             if timed:
                 ev[i][1].record()
             return None
@@ -195,8 +276,9 @@ def main():
             # publish the step's logits: the all-gather of step i runs on RCCL's stream while step i+1 computes;
             # its un-interleave copy is issued one step later (every exchange is finished inside the timed region)
             if pending:
-                gather_logits_finish(pending.pop(), out=gathered)
-            pending.append(gather_logits_start(logits))
+                h, n = pending.pop()
+                gather_logits_finish(h, out=gathered[:n])
+            pending.append((gather_logits_start(logits, n_total=step_total[i % K]), step_total[i % K]))
             return gathered
         return logits
 
@@ -204,10 +286,21 @@ def main():
 
     def drain():
         while pending:
-            gather_logits_finish(pending.pop(), out=gathered)
+            h, n = pending.pop()
+            gather_logits_finish(h, out=gathered[:n])
 
+    # ---- untimed pre-warm: the same pipeline until the wall clock says --prewarm-s (GPU at sustained clocks) ----
+    t_pw = time.perf_counter()
+    n_pw = 0
+    while time.perf_counter() - t_pw < args.prewarm_s:
+        for i in range(20):
+            step((n_pw + i) % K, False)
+        n_pw += 20
+        drain()
+        torch.cuda.synchronize()
+    prewarm_s = time.perf_counter() - t_pw
     for i in range(W):
-        step(i, False)
+        step(i % K, False)
     drain()
     torch.cuda.synchronize()
     if dist:
@@ -215,7 +308,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        out = step(i, True)
+        step(i, True)
     drain()
     torch.cuda.synchronize()
     if dist:
@@ -227,30 +320,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / K
-    net_ms = 0.0 if args.featurize_only else sum(e[1].elapsed_time(e[2]) for e in ev) / K
+    full = [i for i in range(K) if batches[i].shape[0] == B]       # kernel times are quoted on full batches
+    k1_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in full) / max(len(full), 1)
+    net_ms = 0.0 if args.featurize_only else sum(ev[i][1].elapsed_time(ev[i][2]) for i in full) / max(len(full), 1)
 
     if rank == 0:
-        total_clips = world * B * K
-        k1_bytes = BYTES_PER_CLIP_FUSED if fused else BYTES_PER_CLIP
+        total_clips = sum(step_total)
+        k1_bytes = BYTES_PER_CLIP_FUSED[args.dtype] if fused else BYTES_PER_CLIP
         achieved = B * k1_bytes / (k1_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(B, fused)
+        traffic, traffic_src = measured_traffic(B, ("k1_fused_" + args.dtype) if fused else "k1")
+        if args.featurize_only:
+            workload = "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32"
+        elif args.total_clips > 0:
+            workload = (f"configs[3]: {args.total_clips}-clip synthetic stream, every clip distinct, generated on-device "
+                        "from its index, resident in HBM, sharded round-robin, one pass in batches of 4096 per rank -> "
+                        "90x101 features -> CoughDetectorResidual logits, all-gather of logits")
+        else:
+            workload = ("configs[2]: batch=4096 synthetic 1s@16kHz mono per GPU -> 90x101 features "
+                        "(64 mel + 13 MFCC + 13 delta, f32) -> CoughDetectorResidual logits")
         line = {
             "metric": "1s@16kHz clips/sec (featurise+infer)" if not args.featurize_only
                       else "1s@16kHz clips/sec (featurise only)",
             "value": round(total_clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.featurize_only else
-                                           ("bf16 conv (f32 features/stem/accumulate)" if args.dtype == "bf16" else "f32"),
-            "data": "synthetic",
-            "config": {"workload": "configs[2]: batch=4096 synthetic 1s@16kHz mono per GPU -> 90x101 features "
-                                   "(64 mel + 13 MFCC + 13 delta, f32) -> CoughDetectorResidual logits"
-                                   if not args.featurize_only else
-                                   "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32",
-                       "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
-                       "collective": "all_gather(logits) per step, overlapped with the next step" if world > 1 else "none",
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if args.total_clips > 0 else "weak", "vs_baseline": None,
+            "dtype": "f32" if args.featurize_only else DTYPE_LABEL[args.dtype], "data": "synthetic",
+            "prewarm_s": round(prewarm_s, 3),
+            "config": {"workload": workload, "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
+                       "collective": "all_gather(logits) per step, overlapped with the next step" if dist else "none",
+                       "inputs": (f"{len(batches)} distinct device-resident batches" if args.total_clips > 0 else
+                                  f"{max(1, args.rotate)} distinct device-resident batches in rotation "
+                                  f"({max(1, args.rotate) * B * 64000 / 2**20:.0f} MiB)") +
+                                 ", generated on the device (cough_synth_clips)",
                        "weights": "random-init, BN stats randomised"},
-            "roofline": {"kernel": "featurize_kernel<stem fused> (K1+K2)" if fused else "featurize_kernel (K1)",
+            "roofline": {"kernel": f"featurize_kernel<stem fused, {args.dtype}> (K1+K2)" if fused else "featurize_kernel (K1)",
                          "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": round(k1_ms, 4),
@@ -262,10 +365,12 @@ def main():
             line["roofline_classifier"] = {"kernel": "residual blocks + head (K3-K5)" + ("" if fused else " + stem (K2)"),
                                            "bound": "mfma",
                                            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                                           "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4)}
-        if world == 1:
-            line["roofline_stft"] = stft_stage(pre, wav)
-        if world == 1 and args.cpu_seconds > 0:
+                                           "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4),
+                                           "mfma_per_product": MFMA_PER_PRODUCT[args.dtype],
+                                           "mfma_issue_frac": round(MFMA_PER_PRODUCT[args.dtype] * tf / peak, 4)}
+        if world == 1 and not dist:
+            line["roofline_stft"] = stft_stage(pre, [b_ for b_ in batches[:8] if b_.shape[0] == B] or [pool[:B]])
+        if world == 1 and not dist and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if dist:
             sys.stdout.flush()

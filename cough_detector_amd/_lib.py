@@ -29,6 +29,7 @@ SYMBOLS = (
     "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
     "cough_mask_axes", "cough_prepare_clip", "cough_resample", "cough_ring_write", "cough_window_gather",
+    "cough_synth_clips",
 )
 
 
@@ -121,7 +122,8 @@ def load() -> C.CDLL:
         lib.cough_resample.argtypes = [vp, ll, i, i, vp, i, i, i, vp, ll, i, vp]
         lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
         lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]
-        if lib.cough_amd_abi_version() != 2:
+        lib.cough_synth_clips.argtypes = [vp, ll, i, ll, ll, vp]
+        if lib.cough_amd_abi_version() != 3:
             raise RuntimeError("libcough_amd.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcough_amd.so")
-SOURCES = ("api.hip", "featurize.hip", "spectrogram.hip", "resnet.hip", "cnn.hip", "stream.hip")
+SOURCES = ("api.hip", "featurize.hip", "spectrogram.hip", "resnet.hip", "cnn.hip", "stream.hip", "synth.hip")
 FLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

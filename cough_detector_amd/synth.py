@@ -66,6 +66,111 @@ def make_clips(start: int, count: int, stride: int = 1, peak_normalize: bool = T
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Counter-based variant of the same recipe: every sample is a pure function of (seed, sample index), so the clip
+# stream can be generated ON THE DEVICE by any rank (csrc/synth.hip: cough_synth_clips, BASELINE.json configs[3]).
+# This is the host mirror of that kernel -- the same float32 operation sequence -- used to check it sample by sample.
+_M32 = np.uint64(0xFFFFFFFF)
+_F = np.float32
+_TWO_PI = _F(6.28318530717958647692)
+_U24 = _F(5.9604644775390625e-8)
+
+
+def _hash32(x):
+    x = np.asarray(x, dtype=np.uint64) & _M32
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7feb352d)) & _M32
+    x = x ^ (x >> np.uint64(15))
+    x = (x * np.uint64(0x846ca68b)) & _M32
+    return x ^ (x >> np.uint64(16))
+
+
+def _key(seed: int, stream: int, idx):
+    base = _hash32((np.uint64(seed) * np.uint64(0x9E3779B9) + np.uint64(stream)) & _M32)
+    return _hash32((base + np.asarray(idx, dtype=np.uint64)) & _M32)
+
+
+def _u01(k):
+    return (k >> np.uint64(8)).astype(_F) * _U24
+
+
+def _normal(seed: int, stream: int, i):
+    i = np.asarray(i, dtype=np.uint64)
+    u1 = ((_key(seed, stream, 2 * i) >> np.uint64(8)) + np.uint64(1)).astype(_F) * _U24
+    u2 = _u01(_key(seed, stream, 2 * i + 1))
+    return np.sqrt(_F(-2.0) * np.log(u1)) * np.cos(_TWO_PI * u2)
+
+
+def _param(seed: int, p: int):
+    return _F(_u01(_key(seed, 0xF00D, p)))
+
+
+def _tone(f, i):
+    p = _F(f) * (i.astype(_F) * _F(6.25e-5))
+    return np.sin(_TWO_PI * (p - np.floor(p)))
+
+
+def make_clip_counter(seed: int) -> np.ndarray:
+    """Host mirror of ``cough_synth_clips`` (csrc/synth.hip): one un-normalised float32 clip of 16000 samples."""
+    seed64 = int(seed)
+    s = seed64 & 0xFFFFFFFF
+    kind = seed64 % 6
+    i = np.arange(N)
+    if kind == 0:
+        dur = _F(0.3) + _F(0.5) * _param(s, 0)
+        n_burst = int(dur * _F(16000.0))
+        start = int((_param(s, 1) * (_F(1.0) - dur)) * _F(16000.0))
+        n_att = 320
+        f1 = _F(80.0) + _F(70.0) * _param(s, 2)
+        f2 = _F(200.0) + _F(200.0) * _param(s, 3)
+        inv_att, inv_dec = _F(1.0) / _F(n_att - 1), _F(5.0) / _F(n_burst - n_att - 1)
+        j = i - start
+        inside = (j >= 0) & (j < n_burst)
+        env = np.where(j < n_att, j.astype(_F) * inv_att, np.exp(-((j - n_att).astype(_F) * inv_dec)))
+        body = _F(0.7) * _normal(s, 1, i) + _F(0.2) * _tone(f1, i) + _F(0.1) * _tone(f2, i)
+        x = np.where(inside, env * body, _F(0.0)).astype(_F)
+        g = _F(0.8) / (np.abs(x).max() + _F(1e-8))
+        x = x * g + _F(0.01) * _normal(s, 2, i)
+    elif kind == 1:
+        x = _F(0.005) * _normal(s, 1, i)
+    elif kind == 2:
+        x = (_F(0.02) + _F(0.08) * _param(s, 0)) * _normal(s, 1, i)
+    elif kind == 3:
+        f = (50.0, 60.0, 100.0, 120.0)[int(_param(s, 0) * _F(4.0))]
+        x = _F(0.1) * _tone(f, i) + _F(0.02) * _normal(s, 1, i)
+    elif kind == 4:
+        x = _F(0.01) * _normal(s, 1, i)
+        for c in range(1 + int(_param(s, 0) * _F(4.0))):
+            p = int(_param(s, 1 + 2 * c) * _F(N - 100))
+            x[p:p + 50] = _F(-0.3) + _F(0.6) * _param(s, 2 + 2 * c)
+    else:
+        x = np.zeros(N, dtype=_F)
+        for c in range(2 + int(_param(s, 0) * _F(3.0))):
+            f = _F(100.0) + _F(900.0) * _param(s, 1 + 2 * c)
+            a = _F(0.05) + _F(0.1) * _param(s, 2 + 2 * c)
+            x = x + a * _tone(f, i)
+        x = x + _F(0.02) * _normal(s, 1, i)
+    return np.asarray(x, dtype=_F)
+
+
+def device_clips(first_seed: int, count: int, seed_stride: int = 1, device=None, out: "torch.Tensor" = None):
+    """(count, 16000) float32 CUDA tensor of synthetic clips generated on the device by ``cough_synth_clips``
+    (clip j has seed ``first_seed + j*seed_stride``; un-normalised level)."""
+    from . import _lib
+    if not torch.cuda.is_available():
+        raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if out is None:
+        out = torch.empty((count, N), dtype=torch.float32, device=dev)
+    if tuple(out.shape) != (count, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("out must be a (count, 16000) float32 tensor with unit inner stride")
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().cough_synth_clips(out.data_ptr(), out.stride(0) if count > 1 else N, count, int(first_seed),
+                                                 int(seed_stride), torch.cuda.current_stream(out.device).cuda_stream),
+                   "cough_synth_clips")
+    return out
+
+
 def make_stream(seed: int, seconds: float) -> np.ndarray:
     """A mic-like stream: consecutive synthetic clips at un-normalised level."""
     n = int(round(seconds * SAMPLE_RATE))

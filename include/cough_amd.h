@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COUGH_AMD_ABI_VERSION 2
+#define COUGH_AMD_ABI_VERSION 3
 
 #define COUGH_OK 0
 #define COUGH_EINVAL 1        /* bad argument (NULL, negative size, misaligned pointer) */
@@ -241,6 +241,17 @@ int cough_resample(const float* d_in, long long in_stride, int n_rows, int in_le
 #define COUGH_PREP_NORMALIZE 1
 int cough_prepare_clip(const float* d_in, long long in_stride, int n_channels, int n_samples, float* d_out,
                        int out_len, int flags, void* stream);
+
+/* ------------------------------------------------------------------ synthetic clip source (benchmark input)
+ * On-device counterpart of the reference's synthetic data generators
+ * (/root/reference/setup_coughvid.py:381-441, /root/reference/prepare_data.py:136-163) for BASELINE.json
+ * configs[3] ("1M-clip synthetic stream ... generated on-device from seed"): clip c of the call is a pure
+ * function of seed = first_seed + c*seed_stride (mixture by seed % 6: cough-like burst, near silence, white
+ * noise, hum, clicks, speech-like sine stack; un-normalised level), written as 16000 float32 at
+ * d_out + c*stride.  Host mirror with the same float32 operation sequence: cough_detector_amd/synth.py
+ * make_clip_counter. */
+int cough_synth_clips(float* d_out, long long stride, int n_clips, long long first_seed, long long seed_stride,
+                      void* stream);
 
 /* ------------------------------------------------------------------ streaming windows (K6)
  * Device-side counterpart of RealtimePreprocessor.add_audio's FIFO

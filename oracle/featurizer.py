@@ -3,12 +3,15 @@
 Restates ``/root/reference/src/preprocessing.py`` for the configuration the
 reference ships (``/root/reference/src/train.py:264-287``): log-mel(64) +
 MFCC(13) + delta-MFCC(13) -> (1, 90, 101), plus the two cheap optional flags
-(pre-emphasis, delta-delta) and the PCEN branch.  Spectral contrast is not restated
-(the reference's rows are NaN by construction).
+(pre-emphasis, delta-delta), the PCEN branch, the spectral-contrast / centroid rows
+(``extract_spectral_contrast``) and the front of ``process`` (resample, mono, pad / trim).
 
 PARITY UNPINNED against torchaudio: the reference delegates STFT / mel / dB /
 DCT to ``torchaudio.transforms`` (``preprocessing.py:94-127``), which is not
-available in this environment (see ``oracle/__init__.py``).  The functions
+available in this environment (see ``oracle/__init__.py``).  The whole shipped
+chain is, however, cross-checked end to end against code the builder did not
+write (``transformers.audio_utils.spectrogram`` + ``scipy.fft.dct``: 7e-6 on the
+32 golden clips, ``tests/test_oracle_featurizer.py``).  The functions
 below restate torchaudio's published algorithms with the same float32 torch
 op sequence so that the tables are built the way torchaudio builds them:
 

@@ -33,6 +33,50 @@ def test_filterbank_against_transformers_and_float64():
     assert np.abs(fb - tfb).max() < 1e-5
 
 
+def _third_party_features(wav: np.ndarray) -> np.ndarray:
+    """The shipped 90x101 feature image computed WITHOUT any code of this repo: transformers.audio_utils
+    (window_function, mel_filter_bank, spectrogram with its own framing / FFT / mel projection / power_to_db / db_range)
+    + scipy's DCT + numpy for the z-score and the delta.  transformers frames `frame_length = 400` samples after a
+    200-sample reflect pad and zero-pads each frame at the END to 512, torch.stft frames 512 samples after a 256-sample
+    reflect pad with the window centred: the windowed samples are the same, the spectra differ by a time shift, the
+    POWER is the same."""
+    tr = pytest.importorskip("transformers.audio_utils")
+    from scipy.fft import dct
+    win = tr.window_function(400, "hann", periodic=True)
+    fb = tr.mel_filter_bank(257, 64, 100.0, 4000.0, 16000, norm=None, mel_scale="htk")
+    db = tr.spectrogram(wav.astype(np.float64), window=win, frame_length=400, hop_length=160, fft_length=512, power=2.0,
+                        center=True, pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB", reference=1.0,
+                        min_value=1e-10, db_range=80.0, dtype=np.float64)          # (64, 101) dB, per-clip 80 dB floor
+    assert db.shape == (64, 101)
+    mel = np.clip((db + 80.0) / 80.0, 0.0, 1.0)                                    # preprocessing.py:409-410
+    mf = dct(db, type=2, norm="ortho", axis=0)[:13]                                # T.MFCC(log_mels=False): DCT of the dB
+    mf = (mf - mf.mean()) / (mf.std(ddof=1) + 1e-8)                                # preprocessing.py:428 (torch.std: unbiased)
+    pad = np.pad(mf, ((0, 0), (1, 1)), mode="edge")
+    delta = (pad[:, 2:] - pad[:, :-2]) / 2.0                                       # preprocessing.py:342-356
+    return np.concatenate([mel, mf, delta])
+
+
+def test_full_feature_chain_against_third_party_code(features_golden):
+    """F1-F8 end to end against an implementation the builder did not write: the 32 golden clips
+    (the committed fixture) and 12 un-normalised clips recomputed by the oracle.  This does not make the oracle
+    "pinned" to torchaudio, but STFT framing / window / reflect pad, HTK mel bank, dB + per-clip top_db, ortho DCT,
+    unbiased z-score and the custom delta all agree with independent code to float32 rounding."""
+    wav = synth.make_clips(0, len(features_golden["seeds"]))
+    worst_mel = worst_rest = 0.0
+    for k in range(len(wav)):
+        got, ref = _third_party_features(wav[k]), features_golden["features"][k]
+        worst_mel = max(worst_mel, np.abs(got[:64] - ref[:64]).max())
+        worst_rest = max(worst_rest, (np.abs(got[64:] - ref[64:]) / np.maximum(np.abs(ref[64:]), 1.0)).max())
+    quiet = synth.make_clips(300, 12, peak_normalize=False)
+    ref = F.extract_features_batch(torch.from_numpy(quiet)).numpy()
+    for k in range(len(quiet)):
+        got = _third_party_features(quiet[k])
+        worst_mel = max(worst_mel, np.abs(got[:64] - ref[k, :64]).max())
+        worst_rest = max(worst_rest, (np.abs(got[64:] - ref[k, 64:]) / np.maximum(np.abs(ref[k, 64:]), 1.0)).max())
+    print(f"oracle vs transformers+scipy: mel {worst_mel:.2e}, mfcc/delta {worst_rest:.2e}")
+    assert worst_mel < 2e-5 and worst_rest < 2e-5
+
+
 def test_dct_against_scipy():
     from scipy.fft import dct
     d = F.create_dct().numpy()                          # (64, 13)
