@@ -104,6 +104,13 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define K1_STAMP(slot) do { } while (0)
 #endif
 
+#ifdef COUGH_K1_MARKERS
+// Instruction-budget build only (tools/k1_isa_budget.py): phase names as comments in the generated ISA.
+#define K1_MARK(text) asm volatile("; K1MARK " text)
+#else
+#define K1_MARK(text) do { } while (0)
+#endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 
     K1_STAMP(0);
     K1_STAMP(1);
+    K1_MARK("PHASE prologue (window taps, twiddle table, mel taps to registers)");
 
     // ---------------- P1: STFT power -> mel -> dB ----------------
     const int j = lane & 15, fsub = lane >> 4;
@@ -186,7 +194,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     float2 raw[16];
     if constexpr (!PRE_EMPH) load_group(wave, raw);
 
+    K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
     for (int g = wave; g < NGROUP; g += WAVES) {
+        K1_MARK("PHASE P1 peak + window multiply + next group's loads");
         const int t_raw = FPW * g + fsub;
         const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
         const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
@@ -218,9 +228,12 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
             }
         }
+        K1_MARK("PHASE P1 radix-16 #1");
         dft16(a);
+        K1_MARK("PHASE P1 twiddle (LDS table) complex multiply");
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
+        K1_MARK("PHASE P1 16x16 transpose through LDS");
         // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
         float2 z[16];
 #pragma unroll
@@ -234,7 +247,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         wave_lds_fence();
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * XROW + n2];
+        K1_MARK("PHASE P1 radix-16 #2");
         dft16(z);   // z[k2] = Z[j + 16*k2]
+        K1_MARK("PHASE P1 real-input split + |X|^2 -> LDS");
 
         // partner Z[256-k] lives in lane (16-j)&15, register 15-k2 (j>=1) or 16-k2 (j==0)
         float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror (j -> 15 - j), then rotate right by one
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             myx[j + 16 * k2] = xr * xr + xi * xi;
         }
         wave_lds_fence();
+        K1_MARK("PHASE P1 sparse mel + log2 -> LDS");
         // sparse mel: lane = band, the wave's 4 frames
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
@@ -278,6 +294,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         wave_lds_fence();
     }
 
+    K1_MARK("ENDLOOP");
+    K1_MARK("PHASE P2 block max / peak, shift and floor");
     K1_STAMP(2);   // wave 0 finished its frames
     // ---------------- P2: top_db floor, mel rows, DCT, z-score, deltas ----------------
     const float raw_max = block_max(run_max, red, tid);
@@ -290,6 +308,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float floor_db = fmaxf(raw_max - shift, -100.0f) - 80.0f;
     K1_STAMP(3);   // all waves finished P1
     bool wr_mel = wr;
+    K1_MARK("SKIP PCEN branch (off in the shipped configuration)");
     if (pcen) {
         // PCEN branch of extract_mel_spectrogram (preprocessing.py:305-340, :400-404): mel rows =
         // min-max-normalised (mel / (1e-6 + smooth)^0.98 + 2)^0.5 - 2^0.5, smooth = 10-frame moving average
@@ -320,6 +339,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         }
         wr_mel = false;   // the log-mel pass below only prepares the floored dB for the MFCC branch
     }
+    K1_MARK("ENDSKIP");
+    K1_MARK("PHASE P2 floor + mel rows store");
     for (int i2 = tid; i2 < NMEL * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores
         float2 d = reinterpret_cast<float2*>(melbuf)[i2];
         d.x = fmaxf(fmaxf(d.x - shift, -100.0f), floor_db);
@@ -333,6 +354,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     __syncthreads();
     K1_STAMP(4);   // mel rows written
     if (delta_delta == 2) return;   // use_mfcc = False: mel rows only (workgroup-uniform)
+    K1_MARK("PHASE P2 DCT 13x64");
     // DCT: thread = (frame t, coefficient half); coefficients are wave-uniform -> scalar loads
     float* mf = xs;              // [13][101] z-scored MFCC
     float* dl = mf + NMF;        // delta (needed in LDS only for delta-delta)
@@ -350,6 +372,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 if (cc < nc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
         }
     }
+    K1_MARK("PHASE P2 mean / std / z-score");
     float lsum = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 7; ++cc) lsum += (tt < NFRAMES && cc < nc) ? acc[cc] : 0.f;
@@ -369,6 +392,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
     }
     __syncthreads();
+    K1_MARK("PHASE P2 feature image (stem) + MFCC / delta rows");
     // STEM: bf16 feature image(s), row = f + 3, col = t + 3
     uint16_t* img = STEM == 2 ? reinterpret_cast<uint16_t*>(smem + ST_X3_OFF) : reinterpret_cast<uint16_t*>(melbuf);
     uint16_t* img_lo = img + ST_ROWS * ST_PITCH;   // STEM == 2
@@ -434,6 +458,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         // the 2x2 max is a max over 4 accumulator registers of one lane.  STEM == 2: three MFMAs per step
         // (image_hi * w_hi + image_lo * w_hi + image_hi * w_lo), f32 output. ---------------------------------
         __syncthreads();
+        K1_MARK("PHASE K2 stem MFMA + pool + store");
         constexpr int NP = STEM == 2 ? 2 : 1;   // operand planes
         const int sr = lane & 31, sh = lane >> 5;
         bf16x8 bw[NP][4];

@@ -9,9 +9,14 @@
 //
 // One 4-wave workgroup = G clips, <= 75 KB of LDS, so TWO workgroups share a CU and one's staging / epilogue
 // overlaps the other's MFMA phases.
-//   * x is staged once into two un-bordered LDS planes (hi, lo) of 16-byte channel chunks, XOR-swizzled so that
-//     ds_read_b128 of 16 pixels is conflict-free for stride-1 AND stride-2 taps; taps outside the image read a
-//     zero pixel kept at the end of each plane (no border, no predicated fragments).
+//   * x is staged once into two un-bordered LDS planes (hi, lo).  A plane is chunk-planar -- [8-channel chunk][pixel]
+//     of 16-byte cells -- and its pixels are stored parity-split (even / odd image rows x even / odd columns, each
+//     sub-image with the row pitch of the OUTPUT image), so the 32 output pixels of a tile read, for any tap of the
+//     stride-2 conv1 as for the stride-1 conv2 over h, 32 CONSECUTIVE cells of one chunk plane: the 16-lane groups of
+//     a ds_read_b128 cover all 16 residues mod 16, i.e. every fragment read is bank-conflict-free at any alignment
+//     (the XOR-swizzled pixel-major layout measured 2.2x / 1.9x the conflict-free LDS cycles on conv1), and a tap's
+//     address is the tile's base + a compile-time constant.  Taps outside the image read a zero cell kept at the end
+//     of each chunk plane (no border, no predicated fragments).
 //   * conv1 (3x3 s2) accumulates into acc1; the 1x1 s2 projection of x then opens conv2's accumulator acc2, so x is
 //     dead afterwards and h = ReLU(conv1 + b1) is written (split) OVER the x planes; conv2 (3x3 s1) runs out of h.
 //   * wave (mg, ng) owns up to MW 32-pixel tiles x one 32-channel tile; weight fragments (hi, lo) stream from L2 in
@@ -29,11 +34,26 @@
 namespace cough {
 namespace {
 
+#ifdef COUGH_K1_STAMPS
+// diagnostic build only (tools/rb_stamps.py, tools/rbx_stamps.py): per-workgroup s_memtime at phase boundaries, written to
+// a buffer of its own that no other code reads.  Never compiled into libcough_amd.so.
+__device__ unsigned long long* g_rb_stamp_buf = nullptr;
+#define RB_STAMP(slot)                                                                        \
+    do {                                                                                      \
+        if (g_rb_stamp_buf && threadIdx.x == 0)                                               \
+            g_rb_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define RB_STAMP(slot) do { } while (0)
+#endif
+
 struct RbxArgs {
     const float* x;       // [B][XH][XW][CIN] f32 NHWC
     int n_clips;
     const bf16_t* wf;     // MFMA fragments [KS][NT][2 = hi, lo][64 lanes][8]; k-steps: conv1 (9*CIN/16), projection (CIN/16),
                           // conv2 (9*COUT/16); lane (r, h) of (step s, tile t) holds W[32t + r][16s + 8h .. +7] of its operand
+    const bf16_t* wt;     // TAIL: the same weights as 16x16x32 fragments [KS/2][COUT/16][2][64 lanes][8]: lane l of (k32-step q,
+                          // tile t) holds W[16t + (l & 15)][32q + 8(l >> 4) .. +7]
     const float* b1;      // [COUT] folded conv1 bias
     const float* b2;      // [COUT] folded conv2 bias + projection bias
     float* out;           // [B][OH][OW][COUT] f32 NHWC, or nullptr (pipeline: only the fused head reads block 1's output)
@@ -49,20 +69,33 @@ struct RbxCfg {
     static constexpr int WAVES = 4, THREADS = 256;
     static constexpr int OH = (XH - 1) / 2 + 1, OW = (XW - 1) / 2 + 1;
     static constexpr int NPX = XH * XW, PER = OH * OW, M = G * PER;
-    static constexpr int NT = COUT / 32, MG = WAVES / NT, TILES = (M + 31) / 32, MW = (TILES + MG - 1) / MG;
+    static constexpr int NT = COUT / 32, MG = WAVES / NT, TILES = (M + 31) / 32;
+    // TAIL: the last M % 32 <= 16 rows are not padded to a 32-row tile (block 0: 143 rows = 4 tiles + 15 rows would
+    // waste 17 of 160 rows AND leave the waves with 3 / 3 / 2 / 2 tiles); they form one 16-row tile that the four waves
+    // share by channels (16 each) on v_mfma_f32_16x16x32_bf16: every wave then owns FULL / MG 32x32 tiles + one
+    // 16x16 tile -- the same work for each, 143 of 144 rows useful.
+    static constexpr bool TAIL = M % 32 != 0 && M % 32 <= 16 && COUT / 16 == WAVES && (M / 32) % MG == 0 &&
+                                 (9 * CIN / 16) % 2 == 0 && (CIN / 16) % 2 == 0;
+    static constexpr int FULL = TAIL ? M / 32 : TILES;                 // 32-row tiles
+    static constexpr int MW = (FULL + MG - 1) / MG;
     static constexpr int KS1 = 9 * CIN / 16, KSP = CIN / 16, KS2 = 9 * COUT / 16, KS = KS1 + KSP + KS2;
     static constexpr int CHI = CIN / 8, CHO = COUT / 8;
-    static constexpr int DATA = ((G * NPX * CIN * 2 + 255) / 256) * 256;   // bytes of one x plane
-    static constexpr int PL = DATA + 256;                                    // plane pitch: data + the zero pixel
-    static constexpr int ZOFF = DATA;                                        // zero pixel (same offset in both planes)
+    // x planes: parity-split pixel order.  Sub-image (row parity a, column parity b) holds pixels (2i + a, 2j + b) at
+    // i * OW + j; RE / RO = number of even / odd rows; the odd-column sub-images of an odd XW carry one unused column.
+    static constexpr int RE = (XH + 1) / 2, RO = XH / 2;
+    static constexpr int NPP = 2 * XH * OW;                                  // cells of one clip in one chunk plane
+    static constexpr int PB01 = RE * OW, PB10 = 2 * RE * OW, PB11 = 2 * RE * OW + RO * OW;   // sub-image bases (PB00 = 0)
+    static constexpr int CPX = (G * NPP + 1) * 16;                           // bytes of one x chunk plane (+ the zero cell)
+    static constexpr int CPH = (M + 1) * 16;                                 // bytes of one h chunk plane (+ the zero cell)
+    static constexpr int XBYTES = CHI * CPX, HBYTES = CHO * CPH;
+    static constexpr int PL = (((XBYTES > HBYTES ? XBYTES : HBYTES) + 255) / 256) * 256;   // pitch between the hi and lo planes
     static constexpr int BIAS = 2 * PL;                                      // b1[COUT], b2[COUT] f32
     static constexpr int HRED = BIAS + 2 * COUT * 4;                         // head reduction scratch [WAVES][2] f32
     static constexpr int LDS = HRED + WAVES * 2 * 4;
     static constexpr int OP = COUT + 4;                                      // floats per row of the f32 output tile
-    static_assert(WAVES % NT == 0 && MG * MW * 32 >= M, "tile split");
-    static_assert(G * PER * COUT * 2 <= DATA, "the h planes lie over the x planes");
+    static_assert(WAVES % NT == 0 && MG * MW * 32 + (TAIL ? 16 : 0) >= M, "tile split");
+    static_assert(OW == (XW + 1) / 2, "sub-image row pitch");
     static_assert(M * OP * 4 <= 2 * PL, "the output tile lies over the planes");
-    static_assert(PL < 65536, "the lo plane is addressed by a 16-bit immediate offset");
     static_assert((G * NPX * CIN / 4 + THREADS - 1) / THREADS <= 18, "staging registers");
     static_assert(LDS * 2 <= 160 * 1024, "two workgroups per CU");
 };
@@ -82,17 +115,26 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
     lo.x = pk_bf16(a - __uint_as_float(hi.x << 16), b - __uint_as_float(hi.x & 0xffff0000u));
     lo.y = pk_bf16(c - __uint_as_float(hi.y << 16), d - __uint_as_float(hi.y & 0xffff0000u));
 }
-// byte offset of 16-byte chunk L of a plane: chunks are laid out linearly in 256-byte bank rows and the position
-// inside a row is XORed with the row index -- 16 pixels at stride 1 or 2 then touch 16 different 16-byte slots
-__device__ __forceinline__ int swz16(int L) { return ((L & ~15) | ((L ^ (L >> 4)) & 15)) << 4; }
 
 template <int CIN, int COUT, int G, int XH, int XW>
 __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     using Cfg = RbxCfg<CIN, COUT, G, XH, XW>;
     constexpr int THREADS = Cfg::THREADS, OH = Cfg::OH, OW = Cfg::OW, NPX = Cfg::NPX, PER = Cfg::PER, M = Cfg::M;
     constexpr int NT = Cfg::NT, MW = Cfg::MW, KS1 = Cfg::KS1, KSP = Cfg::KSP, KS = Cfg::KS;
-    constexpr int CHI = Cfg::CHI, CHO = Cfg::CHO, PL = Cfg::PL, ZOFF = Cfg::ZOFF, OP = Cfg::OP;
-    constexpr int D = 4;   // weight prefetch depth (k-steps; one k-step = MW x 3 MFMAs >= 192 cycles)
+    constexpr bool TAIL = Cfg::TAIL;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    constexpr int CHI = Cfg::CHI, CHO = Cfg::CHO, PL = Cfg::PL, OP = Cfg::OP, CPX = Cfg::CPX, CPH = Cfg::CPH, NPP = Cfg::NPP;
+    constexpr int ZX = G * NPP * 16, ZH = M * 16;   // byte offset of the zero cell inside an x / h chunk plane
+#ifndef RBX_D
+#define RBX_D 4
+#endif
+#ifndef RBX_PIN
+#define RBX_PIN 1
+#endif
+#ifndef RBX_PRIO
+#define RBX_PRIO 0
+#endif
+    constexpr int D = RBX_D;   // weight prefetch depth (k-steps; one k-step = MW x 3 MFMAs >= 192 cycles)
     extern __shared__ __attribute__((aligned(256))) char smem[];
     float* lbias = reinterpret_cast<float*>(smem + Cfg::BIAS);
 
@@ -100,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     const int ng = wave % NT, mg = wave / NT;
     const int clip0 = blockIdx.x * G;
     const int nvalid = a.n_clips - clip0 < G ? a.n_clips - clip0 : G;
+    RB_STAMP(0);
 
     // ---- weight fragment stream (hi, lo per k-step) -------------------------------------------------------
     const bf16_t* wbase = a.wf + size_t(ng) * 1024 + lane * 8;
@@ -109,6 +152,17 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     bf16x8 ring[D][2];
 #pragma unroll
     for (int i = 0; i < D; ++i) { ring[i][0] = wfrag(i, 0); ring[i][1] = wfrag(i, 1); }
+    // TAIL: this wave's 16 channels (tile `wave`) of the 16-row tile, in k32-steps
+    constexpr int DT = D / 2 > 0 ? D / 2 : 1;
+    const bf16_t* wtbase = TAIL ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
+    auto wtfrag = [&](int q, int plane) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(wtbase + (size_t(q) * Cfg::WAVES * 2 + plane) * 512);
+    };
+    bf16x8 tring[DT][2];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i) { tring[i][0] = wtfrag(i, 0); tring[i][1] = wtfrag(i, 1); }
+    }
 
     // ---- stage: the clips' x (f32) is one linear run of 16-byte pieces = 4 channels of one pixel; all loads are
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
@@ -124,17 +178,20 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             if (i < valid) v[u] = src[i];
         }
         if (tid < COUT) { lbias[tid] = a.b1[tid]; lbias[COUT + tid] = a.b2[tid]; }
-        if (tid < 32) {   // the zero pixel of both planes (256 B each)
-            *reinterpret_cast<uint4*>(smem + ZOFF + (tid & 15) * 16 + (tid >> 4) * PL) = make_uint4(0, 0, 0, 0);
+        if (tid < 2 * CHI) {   // the zero cell of every chunk plane, hi and lo
+            *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = tid + u * THREADS;
             if (i < NPIECE) {
-                const int P = i / QP, q = i % QP;
+                const int P = i / QP, q = i % QP;                      // raster pixel (clip, row, column), quarter-chunk
+                const int g = P / NPX, rem = P % NPX, ih = rem / XW, iw = rem % XW;
+                const int cell = g * NPP + ((ih & 1) ? ((iw & 1) ? Cfg::PB11 : Cfg::PB10) : ((iw & 1) ? Cfg::PB01 : 0)) +
+                                 (ih >> 1) * OW + (iw >> 1);
                 uint2 hi, lo;
                 split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
-                const int off = swz16(P * CHI + (q >> 1)) + (q & 1) * 8;
+                const int off = (q >> 1) * CPX + cell * 16 + (q & 1) * 8;
                 *reinterpret_cast<uint2*>(smem + off) = hi;
                 *reinterpret_cast<uint2*>(smem + off + PL) = lo;
             }
@@ -159,41 +216,86 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         const int g = Rc / PER, rem = Rc % PER;
         goh[mt] = rok[mt] ? rem / OW : -4;   // -4: every tap of a padding row is out of range -> the zero pixel
         gow[mt] = rem % OW;
-        px1[mt] = (g * XH + 2 * goh[mt] - 1) * XW + 2 * gow[mt] - 1;   // x pixel of conv1 tap (0, 0)
-        ph1[mt] = (g * OH + goh[mt] - 1) * OW + gow[mt] - 1;           // h pixel of conv2 tap (0, 0)
+        px1[mt] = (g * NPP + rem) * 16 + h * CPX;   // byte offset of x cell (clip, oh, ow) of sub-image (0, 0), this lane's chunk
+        ph1[mt] = Rc * 16 + h * CPH;                // byte offset of h cell R, this lane's chunk
     }
+    // cell offset of conv1 tap (kh, kw) from cell (oh, ow) of sub-image (0, 0): input (2oh - 1 + kh, 2ow - 1 + kw) lies in
+    // the sub-image of parities ((kh + 1) & 1, (kw + 1) & 1) at (oh - [kh == 0], ow - [kw == 0])
+    auto tapx = [](int kh, int kw) constexpr -> int {
+        const int a = (kh + 1) & 1, b = (kw + 1) & 1;
+        return (a ? (b ? Cfg::PB11 : Cfg::PB10) : (b ? Cfg::PB01 : 0)) - (kh == 0 ? Cfg::OW : 0) - (kw == 0 ? 1 : 0);
+    };
+    // TAIL: lane l owns pixel Rt of the 16-row tile and the 8-channel chunk (l >> 4) of every 32-wide k-step
+    const int tq = lane >> 4;
+    const int Rt = Cfg::FULL * 32 + (lane & 15);
+    const bool rokt = TAIL && Rt < M;
+    int toh = -4, tow = 0, tpx1 = 0, tph1 = 0;
+    if (rokt) {
+        const int g = Rt / PER, rem = Rt % PER;
+        toh = rem / OW;
+        tow = rem % OW;
+        tpx1 = (g * NPP + rem) * 16 + tq * CPX;
+        tph1 = Rt * 16 + tq * CPH;
+    }
+    RB_STAMP(1);
     __syncthreads();
+    RB_STAMP(2);
+#if RBX_PRIO
+    __builtin_amdgcn_s_setprio(1);   // MFMA phases outrank the co-resident workgroup's staging / epilogue VALU work
+#endif
 
     auto body = [&]<int MWX>() {
         f32x16 acc1[MWX], acc2[MWX];
 #pragma unroll
         for (int mt = 0; mt < MWX; ++mt) { acc1[mt] = f32x16{0}; acc2[mt] = f32x16{0}; }
+        f32x4 tacc1 = {0.f, 0.f, 0.f, 0.f}, tacc2 = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 taf[2];
+        int ttadr = 0;
+        // TAIL fragments of k32-step q (q counts 32-wide steps through conv1, projection, conv2)
+        auto tfrag = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr bool conv1 = q < KS1 / 2, proj = !conv1 && q < (KS1 + KSP) / 2;
+            constexpr int kt = conv1 ? q * 32 : proj ? (q - KS1 / 2) * 32 : (q - (KS1 + KSP) / 2) * 32;
+            constexpr int C = (conv1 || proj) ? CIN : COUT, CP = (conv1 || proj) ? CPX : CPH;
+            constexpr int tap = proj ? 4 : kt / C, c32 = (kt % C) / 32, kh = tap / 3, kw = tap % 3;
+            if constexpr (c32 == 0) {
+                if constexpr (conv1 || proj) {
+                    const int ih = 2 * toh - 1 + kh, iw = 2 * tow - 1 + kw;
+                    const bool ok = unsigned(ih) < unsigned(XH) && unsigned(iw) < unsigned(XW);
+                    ttadr = ok ? tpx1 + tapx(kh, kw) * 16 : ZX + tq * CPX;
+                } else {
+                    const int ih = toh - 1 + kh, iw = tow - 1 + kw;
+                    const bool ok = unsigned(ih) < unsigned(OH) && unsigned(iw) < unsigned(OW);
+                    ttadr = ok ? tph1 + ((kh - 1) * OW + kw - 1) * 16 : ZH + tq * CPH;
+                }
+            }
+            const char* p = smem + ttadr + 4 * c32 * CP;
+            taf[0] = *reinterpret_cast<const bf16x8*>(p);
+            taf[1] = *reinterpret_cast<const bf16x8*>(p + PL);
+        };
 
-        // Activation fragments of k-step s (compile-time at every call site).  The pixel-dependent part of the
-        // swizzled address is computed when the first k-step of a tap is fetched; further k-steps of the tap cost
-        // one xor.  The lo plane is the same address + PL (an immediate).
+        // Activation fragments of k-step s (compile-time at every call site).  A tap's address -- the tile's base cell +
+        // a compile-time cell offset, or the zero cell -- is chosen when the first k-step of the tap is fetched; the
+        // further k-steps (chunk planes) and the lo plane are immediate offsets.
         int tadr[MWX];
         auto afrag = [&](auto sc, int mt, bf16x8& fhi, bf16x8& flo) {
             constexpr int s = decltype(sc)::value;
             constexpr bool conv1 = s < KS1, proj = !conv1 && s < KS1 + KSP;
             constexpr int kt = conv1 ? s * 16 : proj ? (s - KS1) * 16 : (s - KS1 - KSP) * 16;   // k inside this operand
-            constexpr int C = (conv1 || proj) ? CIN : COUT, CH = C / 8;
+            constexpr int C = (conv1 || proj) ? CIN : COUT, CP = (conv1 || proj) ? CPX : CPH;
             constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
             if constexpr (c16 == 0) {
-                int P;
-                bool ok;
                 if constexpr (conv1 || proj) {
                     const int ih = 2 * goh[mt] - 1 + kh, iw = 2 * gow[mt] - 1 + kw;
-                    ok = unsigned(ih) < unsigned(XH) && unsigned(iw) < unsigned(XW);
-                    P = px1[mt] + kh * XW + kw;
+                    const bool ok = unsigned(ih) < unsigned(XH) && unsigned(iw) < unsigned(XW);
+                    tadr[mt] = ok ? px1[mt] + tapx(kh, kw) * 16 : ZX + h * CPX;
                 } else {
                     const int ih = goh[mt] - 1 + kh, iw = gow[mt] - 1 + kw;
-                    ok = unsigned(ih) < unsigned(OH) && unsigned(iw) < unsigned(OW);
-                    P = ph1[mt] + kh * OW + kw;
+                    const bool ok = unsigned(ih) < unsigned(OH) && unsigned(iw) < unsigned(OW);
+                    tadr[mt] = ok ? ph1[mt] + ((kh - 1) * OW + kw - 1) * 16 : ZH + h * CPH;
                 }
-                tadr[mt] = ok ? swz16(P * CH + h) : ZOFF + h * 16;
             }
-            const char* p = smem + (tadr[mt] ^ (32 * c16));
+            const char* p = smem + tadr[mt] + 2 * c16 * CP;
             fhi = *reinterpret_cast<const bf16x8*>(p);
             flo = *reinterpret_cast<const bf16x8*>(p + PL);
         };
@@ -205,7 +307,13 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         auto step = [&]<int s>() {
             if constexpr (s == KS1 + KSP) {
                 // ---- x is dead: h = ReLU(conv1 + b1), split, goes over the x planes ----
+                RB_STAMP(3);
+#if RBX_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __syncthreads();
+                if (tid < 2 * CHO)   // the zero cell of every h chunk plane, hi and lo
+                    *reinterpret_cast<uint4*>(smem + (tid / CHO) * PL + (tid % CHO) * CPH + ZH) = make_uint4(0, 0, 0, 0);
 #pragma unroll
                 for (int mt = 0; mt < MWX; ++mt) {
                     const int R = (mg * MW + mt) * 32 + r;
@@ -217,13 +325,29 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                         split4(fmaxf(acc1[mt][4 * gq] + bb.x, 0.f), fmaxf(acc1[mt][4 * gq + 1] + bb.y, 0.f),
                                fmaxf(acc1[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc1[mt][4 * gq + 3] + bb.w, 0.f), hi, lo);
                         if (rok[mt]) {
-                            const int off = swz16(R * CHO + (n0 >> 3)) + h * 8;
+                            const int off = (n0 >> 3) * CPH + R * 16 + h * 8;
                             *reinterpret_cast<uint2*>(smem + off) = hi;
                             *reinterpret_cast<uint2*>(smem + off + PL) = lo;
                         }
                     }
                 }
+                if constexpr (TAIL) {
+                    const int n0 = 16 * wave + 4 * tq;
+                    const float4 bb = *reinterpret_cast<const float4*>(lbias + n0);
+                    uint2 hi, lo;
+                    split4(fmaxf(tacc1[0] + bb.x, 0.f), fmaxf(tacc1[1] + bb.y, 0.f), fmaxf(tacc1[2] + bb.z, 0.f),
+                           fmaxf(tacc1[3] + bb.w, 0.f), hi, lo);
+                    if (rokt) {
+                        const int off = (n0 >> 3) * CPH + Rt * 16 + ((n0 >> 2) & 1) * 8;
+                        *reinterpret_cast<uint2*>(smem + off) = hi;
+                        *reinterpret_cast<uint2*>(smem + off + PL) = lo;
+                    }
+                }
                 __syncthreads();
+                RB_STAMP(4);
+#if RBX_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MWX; ++mt)
                     afrag(std::integral_constant<int, s>{}, mt, af[s & 1][mt][0], af[s & 1][mt][1]);
@@ -239,7 +363,9 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 if constexpr (s + D < KS) {
                     if (mt == 0) { ring[s % D][0] = wfrag(s + D, 0); ring[s % D][1] = wfrag(s + D, 1); }
                 }
+#if RBX_PIN
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if constexpr (s < KS1) {
                     acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][0], acc1[mt], 0, 0, 0);
                     acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][1], acc1[mt], 0, 0, 0);
@@ -249,7 +375,35 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][1], acc2[mt], 0, 0, 0);
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, af[s & 1][mt][0], acc2[mt], 0, 0, 0);
                 }
+#if RBX_PIN
                 __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if constexpr (TAIL) {
+                // the 16-row tile advances one 32-wide k-step per two 16-wide steps: fragments are fetched in the even
+                // step, the three 16x16x32 MFMAs issue in the odd one
+                constexpr int q = s / 2;
+                if constexpr (s % 2 == 0) {
+                    tfrag(std::integral_constant<int, q>{});
+                } else {
+                    const bf16x8 twhi = tring[q % DT][0], twlo = tring[q % DT][1];
+                    if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
+#if RBX_PIN
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    if constexpr (s < KS1) {
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[0], tacc1, 0, 0, 0);
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[1], tacc1, 0, 0, 0);
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo, taf[0], tacc1, 0, 0, 0);
+                    } else {
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[0], tacc2, 0, 0, 0);
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[1], tacc2, 0, 0, 0);
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo, taf[0], tacc2, 0, 0, 0);
+                    }
+#if RBX_PIN
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
             }
         };
         [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
@@ -257,6 +411,10 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         }(std::make_integer_sequence<int, KS>{});
 
         // ---- epilogue: out = ReLU(conv2 + projection + b2) -> f32 [pixel][COUT] tile over the (dead) planes ----
+        RB_STAMP(5);
+#if RBX_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -271,9 +429,16 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 if (rok[mt]) *reinterpret_cast<float4*>(otile + R * OP + n0) = o;
             }
         }
+        if constexpr (TAIL) {
+            const int n0 = 16 * wave + 4 * tq;
+            const float4 bb = *reinterpret_cast<const float4*>(lbias + COUT + n0);
+            const float4 o = make_float4(fmaxf(tacc2[0] + bb.x, 0.f), fmaxf(tacc2[1] + bb.y, 0.f),
+                                         fmaxf(tacc2[2] + bb.z, 0.f), fmaxf(tacc2[3] + bb.w, 0.f));
+            if (rokt) *reinterpret_cast<float4*>(otile + Rt * OP + n0) = o;
+        }
     };
     // a wave whose last tile lies entirely beyond the M valid rows runs the shorter body (one wave-uniform choice)
-    constexpr int TILES = Cfg::TILES;
+    constexpr int TILES = Cfg::FULL;
     const int mytiles = TILES - mg * MW < MW ? TILES - mg * MW : MW;
     if constexpr (MW > 1 && TILES % MW != 0) {
         if (mytiles < MW) body.template operator()<(TILES % MW)>();
@@ -282,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         body.template operator()<MW>();
     }
     __syncthreads();
+    RB_STAMP(6);
     const float* otile = reinterpret_cast<const float*>(smem);
     if (a.out != nullptr) {
         const int nvec = nvalid * PER * (COUT / 4);
@@ -321,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             }
         }
     }
+    RB_STAMP(7);
 }
 
 // Host: folded [N][K] weights of conv1, projection and conv2 -> split-bf16 MFMA fragments in stream order.
@@ -343,6 +510,30 @@ inline void pack_x3_fragments(std::vector<bf16_t>& wf, const std::vector<float>&
                     const size_t base = ((size_t(s) * nt + t) * 2) * 512 + size_t(lane) * 8 + jj;
                     wf[base] = hi;
                     wf[base + 512] = f2bf_host(v - hf);
+                }
+    }
+}
+
+// Host: the same weights as 16x16x32 fragments for the TAIL tile ([KS/2][N/16][2][64 lanes][8], resblock_x3_kernel).
+inline void pack_x3_tail_fragments(std::vector<bf16_t>& wt, const std::vector<float>& w1, int K1, const std::vector<float>& wp,
+                                   int KP, const std::vector<float>& w2, int K2, int N) {
+    const int nt = N / 16, q1 = K1 / 32, qp = KP / 32, q2 = K2 / 32, nq = q1 + qp + q2;
+    wt.assign(size_t(nq) * nt * 2 * 512, 0);
+    for (int q = 0; q < nq; ++q) {
+        const std::vector<float>& w = q < q1 ? w1 : q < q1 + qp ? wp : w2;
+        const int K = q < q1 ? K1 : q < q1 + qp ? KP : K2;
+        const int ql = q < q1 ? q : q < q1 + qp ? q - q1 : q - q1 - qp;
+        for (int t = 0; t < nt; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float v = w[size_t(16 * t + (lane & 15)) * K + 32 * ql + 8 * (lane >> 4) + jj];
+                    const bf16_t hi = f2bf_host(v);
+                    const uint32_t hb = uint32_t(hi) << 16;
+                    float hf;
+                    std::memcpy(&hf, &hb, 4);
+                    const size_t base = ((size_t(q) * nt + t) * 2) * 512 + size_t(lane) * 8 + jj;
+                    wt[base] = hi;
+                    wt[base + 512] = f2bf_host(v - hf);
                 }
     }
 }

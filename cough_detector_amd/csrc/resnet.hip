@@ -354,18 +354,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
 // GEMM view per workgroup: M = G*OH*OW output pixels (32-row MFMA tiles), N = COUT, K = 9*CIN then
 // 9*COUT + CIN.  Wave (mg, ng) owns MW M-tiles x NW N-tiles.
 
-#ifdef COUGH_K1_STAMPS
-// diagnostic build only (tools/rb_stamps.py): per-workgroup s_memtime at phase boundaries
-__device__ unsigned long long* g_rb_stamp_buf = nullptr;
-#define RB_STAMP(slot)                                                                        \
-    do {                                                                                      \
-        if (g_rb_stamp_buf && threadIdx.x == 0)                                               \
-            g_rb_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define RB_STAMP(slot) do { } while (0)
-#endif
-
 constexpr int WREP = 4;   // replicas of the fragment-packed weights (L2 channel spreading)
 
 struct RbArgs {
@@ -798,6 +786,7 @@ struct cough_resnet {
     void* d_w[4];          // packed [N][Ktot]: b0.conv1, b0.conv2+skip, b1.conv1, b1.conv2+skip
     cough::bf16_t* d_wfrag[4];   // bf16 mode: the same weights as MFMA fragments [K/16][N/32][64][8] (fused block kernels)
     cough::bf16_t* d_wx3[2];     // bf16x3 mode: split-bf16 fragments of block i (conv1, projection, conv2; resblock_x3.h)
+    cough::bf16_t* d_wx3t[2];    //   ... and the 16x16x32 fragments of the 16-row tail tile (block 0)
     float* d_b[4];
     int ktot[4];
     float* d_fcw;          // [2][128]
@@ -815,9 +804,12 @@ int upload(void** dst, const std::vector<T>& v) {
 }
 
 int upload_x3(cough_resnet* m, int blk, const FoldedConv& c1, const FoldedConv& c2, const FoldedConv& sk) {
-    std::vector<bf16_t> wf;
+    std::vector<bf16_t> wf, wt;
     pack_x3_fragments(wf, c1.w, 9 * c1.C, sk.w, sk.C, c2.w, 9 * c2.C, c1.N);
-    return upload(reinterpret_cast<void**>(&m->d_wx3[blk]), wf);
+    if (int e = upload(reinterpret_cast<void**>(&m->d_wx3[blk]), wf)) return e;
+    if ((9 * c1.C) % 32 != 0 || sk.C % 32 != 0) return COUGH_OK;   // no 32-wide k-steps: the kernel has no tail tile
+    pack_x3_tail_fragments(wt, c1.w, 9 * c1.C, sk.w, sk.C, c2.w, 9 * c2.C, c1.N);
+    return upload(reinterpret_cast<void**>(&m->d_wx3t[blk]), wt);
 }
 
 int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const FoldedConv* skip) {
@@ -932,6 +924,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                 ra.x = reinterpret_cast<const float*>(k.x);
                 ra.n_clips = n;
                 ra.wf = m->d_wx3[i];
+                ra.wt = m->d_wx3t[i];
                 ra.b1 = m->d_b[k.s1];
                 ra.b2 = m->d_b[k.s2];
                 ra.out = reinterpret_cast<float*>(k.out);
@@ -1123,6 +1116,8 @@ extern "C" void cough_resnet_destroy(cough_resnet* m) {
     }
     (void)hipFree(m->d_wx3[0]);
     (void)hipFree(m->d_wx3[1]);
+    (void)hipFree(m->d_wx3t[0]);
+    (void)hipFree(m->d_wx3t[1]);
     (void)hipFree(m->d_fcw);
     (void)hipFree(m->d_fcb);
     delete m;

@@ -28,11 +28,14 @@ __device__ __forceinline__ float normal(uint32_t seed, uint32_t stream, int i) {
     return sqrtf(-2.0f * logf(u1)) * cosf(TWO_PI * u2);
 }
 __device__ __forceinline__ float param(uint32_t seed, int p) { return u01(key(seed, 0xF00Du, uint32_t(p))); }
-// sin(2*pi*f*t) at sample i with the phase reduced before the sine (float32 keeps its accuracy at 1 kHz x 1 s)
-__device__ __forceinline__ float tone(float f, int i) {
-    const float p = __fmul_rn(f, __fmul_rn(float(i), 6.25e-5f));
-    return sinf(TWO_PI * (p - floorf(p)));
+// sin(2*pi*f*t) at sample i for a frequency of fq/16 Hz: the phase f*i/16000 = fq*i/256000 is reduced in exact
+// integer arithmetic (fq <= 16000, i < 16000: the product fits 32 bits), so it carries no float32 rounding of a
+// large argument and the host mirror reproduces it bit for bit
+__device__ __forceinline__ float tone(int fq, int i) {
+    const uint32_t r = (uint32_t(fq) * uint32_t(i)) % 256000u;
+    return sinf(TWO_PI * __fmul_rn(float(r), 3.90625e-6f));
 }
+__device__ __forceinline__ int freq16(float lo16, float span16, float x) { return int(__fadd_rn(lo16, __fmul_rn(span16, x))); }
 // parameter arithmetic is pinned to separate IEEE multiplies / adds (no FMA contraction): the host mirror must
 // reproduce every floor() below exactly
 __device__ __forceinline__ float affine(float a, float b, float x) { return __fadd_rn(a, __fmul_rn(b, x)); }
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
         const int n_burst = int(__fmul_rn(dur, 16000.0f));
         const int start = int(__fmul_rn(__fmul_rn(param(seed, 1), __fsub_rn(1.0f, dur)), 16000.0f));
         const int n_att = 320;
-        const float f1 = affine(80.0f, 70.0f, param(seed, 2)), f2 = affine(200.0f, 200.0f, param(seed, 3));
+        const int f1 = freq16(1280.0f, 1120.0f, param(seed, 2)), f2 = freq16(3200.0f, 3200.0f, param(seed, 3));   // 80-150, 200-400 Hz
         const float inv_att = 1.0f / float(n_att - 1), inv_dec = 5.0f / float(n_burst - n_att - 1);
         float mx = 0.f;
         for (int i = tid; i < SN; i += 256) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
         for (int i = tid; i < SN; i += 256) o[i] = sigma * normal(seed, 1, i);
     } else if (kind == 3) {   // mains-like hum
         const int sel = int(__fmul_rn(param(seed, 0), 4.0f));
-        const float f = sel == 0 ? 50.0f : sel == 1 ? 60.0f : sel == 2 ? 100.0f : 120.0f;
+        const int f = sel == 0 ? 800 : sel == 1 ? 960 : sel == 2 ? 1600 : 1920;   // 50 / 60 / 100 / 120 Hz
         for (int i = tid; i < SN; i += 256) o[i] = 0.1f * tone(f, i) + 0.02f * normal(seed, 1, i);
     } else if (kind == 4) {   // clicks on a floor: 1-4 plateaus of 50 samples, later ones overwrite earlier ones
         const int cnt = 1 + int(__fmul_rn(param(seed, 0), 4.0f));
@@ -96,10 +99,11 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
         }
     } else {                  // speech-like stack of 2-4 sines
         const int cnt = 2 + int(__fmul_rn(param(seed, 0), 3.0f));
-        float f[4], a[4];
+        int f[4];
+        float a[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f[c] = affine(100.0f, 900.0f, param(seed, 1 + 2 * c));
+            f[c] = freq16(1600.0f, 14400.0f, param(seed, 1 + 2 * c));   // 100-1000 Hz
             a[c] = affine(0.05f, 0.1f, param(seed, 2 + 2 * c));
         }
         for (int i = tid; i < SN; i += 256) {

@@ -105,9 +105,14 @@ def _param(seed: int, p: int):
     return _F(_u01(_key(seed, 0xF00D, p)))
 
 
-def _tone(f, i):
-    p = _F(f) * (i.astype(_F) * _F(6.25e-5))
-    return np.sin(_TWO_PI * (p - np.floor(p)))
+def _tone(fq: int, i):
+    """sin(2 pi f t) for f = fq/16 Hz: phase fq*i/256000 reduced in exact integer arithmetic."""
+    r = (np.uint64(fq) * i.astype(np.uint64)) % np.uint64(256000)
+    return np.sin(_TWO_PI * (r.astype(_F) * _F(3.90625e-6)))
+
+
+def _freq16(lo16: float, span16: float, x) -> int:
+    return int(_F(lo16) + _F(span16) * x)
 
 
 def make_clip_counter(seed: int) -> np.ndarray:
@@ -121,8 +126,8 @@ def make_clip_counter(seed: int) -> np.ndarray:
         n_burst = int(dur * _F(16000.0))
         start = int((_param(s, 1) * (_F(1.0) - dur)) * _F(16000.0))
         n_att = 320
-        f1 = _F(80.0) + _F(70.0) * _param(s, 2)
-        f2 = _F(200.0) + _F(200.0) * _param(s, 3)
+        f1 = _freq16(1280.0, 1120.0, _param(s, 2))           # 80-150 Hz in 1/16 Hz
+        f2 = _freq16(3200.0, 3200.0, _param(s, 3))           # 200-400 Hz
         inv_att, inv_dec = _F(1.0) / _F(n_att - 1), _F(5.0) / _F(n_burst - n_att - 1)
         j = i - start
         inside = (j >= 0) & (j < n_burst)
@@ -136,7 +141,7 @@ def make_clip_counter(seed: int) -> np.ndarray:
     elif kind == 2:
         x = (_F(0.02) + _F(0.08) * _param(s, 0)) * _normal(s, 1, i)
     elif kind == 3:
-        f = (50.0, 60.0, 100.0, 120.0)[int(_param(s, 0) * _F(4.0))]
+        f = (800, 960, 1600, 1920)[int(_param(s, 0) * _F(4.0))]        # 50 / 60 / 100 / 120 Hz
         x = _F(0.1) * _tone(f, i) + _F(0.02) * _normal(s, 1, i)
     elif kind == 4:
         x = _F(0.01) * _normal(s, 1, i)
@@ -146,7 +151,7 @@ def make_clip_counter(seed: int) -> np.ndarray:
     else:
         x = np.zeros(N, dtype=_F)
         for c in range(2 + int(_param(s, 0) * _F(3.0))):
-            f = _F(100.0) + _F(900.0) * _param(s, 1 + 2 * c)
+            f = _freq16(1600.0, 14400.0, _param(s, 1 + 2 * c))   # 100-1000 Hz
             a = _F(0.05) + _F(0.1) * _param(s, 2 + 2 * c)
             x = x + a * _tone(f, i)
         x = x + _F(0.02) * _normal(s, 1, i)
@@ -164,6 +169,8 @@ def device_clips(first_seed: int, count: int, seed_stride: int = 1, device=None,
         out = torch.empty((count, N), dtype=torch.float32, device=dev)
     if tuple(out.shape) != (count, N) or out.dtype != torch.float32 or out.stride(1) != 1:
         raise ValueError("out must be a (count, 16000) float32 tensor with unit inner stride")
+    if count == 0:
+        return out
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().cough_synth_clips(out.data_ptr(), out.stride(0) if count > 1 else N, count, int(first_seed),
                                                  int(seed_stride), torch.cuda.current_stream(out.device).cuda_stream),
