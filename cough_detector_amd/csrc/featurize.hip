@@ -106,7 +106,12 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 
 #ifdef COUGH_K1_MARKERS
 // Instruction-budget build only (tools/k1_isa_budget.py): phase names as comments in the generated ISA.
-#define K1_MARK(text) asm volatile("; K1MARK " text)
+#define K1_MARK(text)                             \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("; K1MARK " text);           \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
 #else
 #define K1_MARK(text) do { } while (0)
 #endif
@@ -179,9 +184,12 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
         const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
         if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
+            K1_MARK("WEIGHT 0.885 (23 of 26 groups: frames inside the clip)");
 #pragma unroll
             for (int n1 = 1; n1 < 15; ++n1) raw[n1] = *reinterpret_cast<const float2*>(x + s0 + 32 * n1);
+            K1_MARK("ENDWEIGHT");
         } else {   // frames 0,1,99,100 reach into the reflect padding of torch.stft(center=True)
+            K1_MARK("WEIGHT 0.115 (3 of 26 groups: reflected edge frames)");
 #pragma unroll
             for (int n1 = 1; n1 < 15; ++n1) {
                 int i0 = s0 + 32 * n1, i1 = i0 + 1;
@@ -189,6 +197,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
                 raw[n1] = make_float2(x[i0], x[i1]);
             }
+            K1_MARK("ENDWEIGHT");
         }
     };
     float2 raw[16];

@@ -3,8 +3,9 @@
 
     python tools/k1_isa_budget.py [--kernel plain|bf16|bf16x3] > profiles/r02_k1_isa_budget.txt
 
-Compiles csrc/featurize.hip with -DCOUGH_K1_MARKERS -save-temps (the markers are ISA comments: no instruction is
-added), cuts the chosen instantiation's instruction stream at the markers and counts wave-instructions per phase and
+Compiles csrc/featurize.hip with -DCOUGH_K1_MARKERS -save-temps (the markers are ISA comments between two scheduling
+barriers: no instruction is added, but the scheduler cannot move instructions across a phase boundary, so the counts
+are attributable -- the production build differs from this one only in instruction ORDER), cuts the chosen instantiation's instruction stream at the markers and counts wave-instructions per phase and
 class.  Dynamic counts = static counts x the trip count of the enclosing loop: the P1 loop runs 26 four-frame groups
 over 4 waves = 6.5 iterations per wave; everything the compiler left as a loop inside a phase is reported with its
 static size and back-edge so that the trip count can be read from the source.  Sections between SKIP / ENDSKIP markers
@@ -59,7 +60,7 @@ def main():
     start = next(i for i, l in enumerate(text) if l.startswith("_ZN5cough") and KERNELS[args.kernel] in l.split(":")[0] and ": ; @" in l)
     end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
     phases, order = {}, []
-    cur, mult, skip = "entry", 1.0, False
+    cur, mult, skip, weight = "entry", 1.0, False, 1.0
     labels, loops = {}, []
     for ln in range(start + 1, end + 1):
         l = text[ln].strip()
@@ -75,6 +76,10 @@ def main():
                 skip = True
             elif body.startswith("ENDSKIP"):
                 skip = False
+            elif body.startswith("WEIGHT"):
+                weight = float(body.split()[1])
+            elif body.startswith("ENDWEIGHT"):
+                weight = 1.0
             continue
         if not l or l.startswith((";", ".")) and not l.startswith(".LBB"):
             continue
@@ -89,7 +94,7 @@ def main():
             phases[key] = {"mult": mult, "static": {}}
             order.append(key)
         c = classify(op)
-        phases[key]["static"][c] = phases[key]["static"].get(c, 0) + 1
+        phases[key]["static"][c] = phases[key]["static"].get(c, 0) + weight
         m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)|s_branch\s+(\.LBB\d+_\d+)", l)
         if m:
             tgt = m.group(1) or m.group(2)
