@@ -34,6 +34,8 @@ SHIPPED_FLAGS = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=Fal
 
 
 class MultiStreamDetector:
+    SPIN_QUERIES = 200        # bounded poll of the tick's completion event before falling back to a blocking wait
+
     def __init__(self, model, n_streams: int, sample_rate: int = 16000, window_duration: float = 1.0,
                  hop_duration: float = 0.25, confidence_threshold: float = 0.5, smoothing_window: int = 3,
                  debounce_seconds: float = 0.5, clock: Optional[Callable[[], float]] = None,
@@ -151,8 +153,15 @@ class MultiStreamDetector:
         g["full"].replay()
         g["done"].record()
         self.next_start += self.hop
-        while not g["done"].query():                                        # the one host sync of the tick; polled:
-            pass                                                            # an interrupt-driven wait costs ~50 us
+        # The one host sync of the tick.  The graph's GPU time is ~0.1 ms and an interrupt-driven wait costs ~50 us,
+        # so the event is polled -- but only for a bounded number of queries (~0.3 ms): with one rank per GPU on a
+        # shared cgroup (8 ranks on 16 cores, next to RCCL's proxy threads) an unbounded spin would burn a core
+        # whenever the device is slow; past the bound the host sleeps in event.synchronize().
+        for _ in range(self.SPIN_QUERIES):
+            if g["done"].query():
+                break
+        else:
+            g["done"].synchronize()
         return g["h_probs"].numpy()[:, 1].copy()
 
     def _decide(self, w_ids, p) -> List[Tuple[int, float, float]]:

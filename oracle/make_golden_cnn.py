@@ -5,8 +5,9 @@ Run in the BUILD CONTAINER only (needs ``/root/reference``):  ``python -m oracle
 Executes the REFERENCE modules ``CoughDetector`` ("standard") and ``CoughDetectorSmall`` ("small") of
 ``/root/reference/src/model.py`` (imported by file path; torch only) in eval mode on the first 8 feature images
 of ``features_golden.npz``: seeded weights, BatchNorm statistics and affine parameters randomised (fresh 0/1 stats
-would not exercise the folding), Linear weights x8 (default init leaves the class margins at ~1e-4), last-layer
-bias shifted so that both classes occur.  Stored per model: the
+would not exercise the folding), Linear weights x8 (default init leaves the class margins at ~1e-4), then the last
+Linear scaled and re-centred to a TRAINED head's logit scale (class-margin std 2.5, as resnet_golden.npz), margin
+median at 0 so that both classes occur.  Stored per model: the
 state_dict, the conv-stack output before the global mean, logits, softmax, argmax.
 """
 from __future__ import annotations
@@ -48,9 +49,14 @@ def main():
             elif isinstance(m, torch.nn.Linear):
                 m.weight.data.mul_(8.0)                                        # default init gives margins ~1e-4
         with torch.no_grad():
+            # trained-scale head (as oracle/make_golden.py): class-margin std 2.5, logits centred, margin median at 0
+            lastm = dict(net.named_modules())[last]
+            l = net(x)
+            lastm.weight.data.mul_(2.5 / (l[:, 1] - l[:, 0]).std())
+            lastm.bias.data.sub_(net(x).mean(dim=0))
             l = net(x)
             d = (l[:, 1] - l[:, 0]).sort().values
-            dict(net.named_modules())[last].bias.data[1] -= 0.5 * (d[N // 2 - 1] + d[N // 2])
+            lastm.bias.data[1] -= 0.5 * (d[N // 2 - 1] + d[N // 2])
             conv_out = net.conv_layers(x) if kind == "standard" else net.features[:-1](x)
             logits = net(x)
             preds, probs = net.predict(x)

@@ -170,3 +170,39 @@ def test_graph_replay_equals_eager_launches():
     assert used and not unused                            # the graph path really ran
     assert all(len(p) == 9 for p in pg)
     assert pg == pe and eg == ee
+
+
+def test_64_streams_config4_against_per_stream_oracles():
+    """BASELINE.json configs[4]: 64 concurrent mic-like streams, 0.1 s chunks, 1 s window / 0.25 s hop, through the
+    captured-graph steady state, split-bf16 classifier with a trained-scale head; every stream's window
+    probabilities and detections against its own CPU oracle (R0 + M5 + S0 semantics)."""
+    from cough_detector_amd.streaming import MultiStreamDetector
+    from parity import realistic_state_dict
+    sd = realistic_state_dict(5)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    S, seconds = 64, 2.5
+    now = {"t": 0.0}
+    det = MultiStreamDetector(model, S, confidence_threshold=0.5, smoothing_window=3, debounce_seconds=0.5,
+                              clock=lambda: now["t"])
+    refs = [oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"]) for _ in range(S)]
+    streams = np.stack([synth.make_stream(500 + s, seconds) for s in range(S)])
+    got_events, ref_events = [], []
+    for i in range(0, streams.shape[1], 1600):
+        now["t"] = (i + 1600) / 16000.0
+        got_events.append(sorted(d[0] for d in det.push(streams[:, i:i + 1600])))
+        ref_events.append(sorted(s for s in range(S) if refs[s].process_audio_chunk(streams[s, i:i + 1600]) is not None))
+    assert det._g is not None                                 # the captured steady state really ran
+    worst = 0.0
+    for s in range(S):
+        assert len(det.window_probs[s]) == len(refs[s].window_probs) == 7
+        worst = max(worst, float(np.abs(np.array(det.window_probs[s]) - np.array(refs[s].window_probs)).max()))
+    print(f"64 streams x 7 windows: max |prob - oracle| {worst:.2e}; detections {sum(map(len, got_events))}")
+    assert worst < 1e-3
+    assert got_events == ref_events and sum(map(len, got_events)) > 0
+    # the bounded poll falls back to a blocking wait without changing results
+    det2 = MultiStreamDetector(model, S, confidence_threshold=2.0, clock=lambda: 0.0)
+    det2.SPIN_QUERIES = 0
+    for i in range(0, 24000, 1600):
+        det2.push(streams[:, i:i + 1600])
+    assert [p[:3] for p in det2.window_probs] == [p[:3] for p in det.window_probs]
