@@ -215,7 +215,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         if constexpr (!PRE_EMPH) {
 #pragma unroll
             for (int n1 = 1; n1 < 15; ++n1) {
-                peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));
+                peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));   // one v_max3_f32 with |.| modifiers
                 a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
             }
             // the raw registers are free again: the next group's samples start moving now and land while
