@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
 #define RBX_D 4
 #endif
 #ifndef RBX_PIN
-#define RBX_PIN 1
+#define RBX_PIN 1   // (the 16-row tile's pins; the 32-row tiles are always pinned, see the k-loop)
 #endif
 #ifndef RBX_PRIO
 #define RBX_PRIO 0
@@ -299,6 +299,26 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             fhi = *reinterpret_cast<const bf16x8*>(p);
             flo = *reinterpret_cast<const bf16x8*>(p + PL);
         };
+        // the address part of afrag alone (the k-loop issues the two reads separately, one in front of each MFMA)
+        auto aaddr = [&](auto sc, int mt) -> const char* {
+            constexpr int s = decltype(sc)::value;
+            constexpr bool conv1 = s < KS1, proj = !conv1 && s < KS1 + KSP;
+            constexpr int kt = conv1 ? s * 16 : proj ? (s - KS1) * 16 : (s - KS1 - KSP) * 16;
+            constexpr int C = (conv1 || proj) ? CIN : COUT, CP = (conv1 || proj) ? CPX : CPH;
+            constexpr int tap = proj ? 4 : kt / C, c16 = (kt % C) / 16, kh = tap / 3, kw = tap % 3;
+            if constexpr (c16 == 0) {
+                if constexpr (conv1 || proj) {
+                    const int ih = 2 * goh[mt] - 1 + kh, iw = 2 * gow[mt] - 1 + kw;
+                    const bool ok = unsigned(ih) < unsigned(XH) && unsigned(iw) < unsigned(XW);
+                    tadr[mt] = ok ? px1[mt] + tapx(kh, kw) * 16 : ZX + h * CPX;
+                } else {
+                    const int ih = goh[mt] - 1 + kh, iw = gow[mt] - 1 + kw;
+                    const bool ok = unsigned(ih) < unsigned(OH) && unsigned(iw) < unsigned(OW);
+                    tadr[mt] = ok ? ph1[mt] + ((kh - 1) * OW + kw - 1) * 16 : ZH + h * CPH;
+                }
+            }
+            return smem + tadr[mt] + 2 * c16 * CP;
+        };
 
         bf16x8 af[2][MWX][2];
 #pragma unroll
@@ -352,32 +372,34 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 for (int mt = 0; mt < MWX; ++mt)
                     afrag(std::integral_constant<int, s>{}, mt, af[s & 1][mt][0], af[s & 1][mt][1]);
             }
-            // Software pipeline, pinned with scheduling barriers: ahead of the three MFMAs of tile mt sit the address
-            // math + two ds_reads of the NEXT step's fragments of tile mt (and, once per step, the weight loads D steps
-            // ahead); left alone, the scheduler sinks every ds_read next to its MFMA and each pays the LDS latency.
+            // Software pipeline, pinned with scheduling barriers: ONE filler sits in front of EACH MFMA of tile mt -- the
+            // address math of the next step's fragment, then its hi read (+ the hi weight load D steps ahead), then its lo
+            // read (+ the lo weight load) -- so that no filler group is longer than the ~24 issue cycles an MFMA leaves
+            // free.  Left alone, the scheduler sinks every ds_read next to its MFMA and each pays the LDS latency; one
+            // filler group per MFMA triple (the first version) left the pipe idle behind every third MFMA (+2.3 %).
             const bf16x8 whi = ring[s % D][0], wlo = ring[s % D][1];
 #pragma unroll
             for (int mt = 0; mt < MWX; ++mt) {
-                if constexpr (s + 1 < KS && s + 1 != KS1 + KSP)
-                    afrag(std::integral_constant<int, s + 1>{}, mt, af[(s + 1) & 1][mt][0], af[(s + 1) & 1][mt][1]);
-                if constexpr (s + D < KS) {
-                    if (mt == 0) { ring[s % D][0] = wfrag(s + D, 0); ring[s % D][1] = wfrag(s + D, 1); }
-                }
-#if RBX_PIN
+                constexpr bool pf = s + 1 < KS && s + 1 != KS1 + KSP;
+                const bf16x8 cur_hi = af[s & 1][mt][0], cur_lo = af[s & 1][mt][1];
+                const char* np = nullptr;
+                if constexpr (pf) np = aaddr(std::integral_constant<int, s + 1>{}, mt);
                 __builtin_amdgcn_sched_barrier(0);
-#endif
-                if constexpr (s < KS1) {
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][0], acc1[mt], 0, 0, 0);
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][1], acc1[mt], 0, 0, 0);
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, af[s & 1][mt][0], acc1[mt], 0, 0, 0);
-                } else {
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][0], acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, af[s & 1][mt][1], acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, af[s & 1][mt][0], acc2[mt], 0, 0, 0);
-                }
-#if RBX_PIN
+                if constexpr (s < KS1) acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, cur_hi, acc1[mt], 0, 0, 0);
+                else acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, cur_hi, acc2[mt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#endif
+                if constexpr (pf) af[(s + 1) & 1][mt][0] = *reinterpret_cast<const bf16x8*>(np);
+                if constexpr (s + D < KS) { if (mt == 0) ring[s % D][0] = wfrag(s + D, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s < KS1) acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, cur_lo, acc1[mt], 0, 0, 0);
+                else acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, cur_lo, acc2[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (pf) af[(s + 1) & 1][mt][1] = *reinterpret_cast<const bf16x8*>(np + PL);
+                if constexpr (s + D < KS) { if (mt == 0) ring[s % D][1] = wfrag(s + D, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s < KS1) acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, cur_hi, acc1[mt], 0, 0, 0);
+                else acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, cur_hi, acc2[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (TAIL) {
                 // the 16-row tile advances one 32-wide k-step per two 16-wide steps: fragments are fetched in the even

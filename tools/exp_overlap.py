@@ -25,7 +25,7 @@ def main():
     dev = torch.device("cuda:0")
     pre = AudioPreprocessor(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False,
                             use_spectral_contrast=False, device="cuda")
-    model = create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+    model = create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=os.environ.get("COUGH_EXP_DTYPE", "bf16x3"))
     model.load_state_dict(random_state_dict(seed=3))
     model.to(dev).eval()
     wav = torch.from_numpy(make_clips(0, args.batch, peak_normalize=False)).to(dev)
