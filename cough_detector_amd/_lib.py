@@ -24,7 +24,7 @@ SYMBOLS = (
     "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
     "cough_featurizer_num_frames", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
     "cough_spectrogram",
-    "cough_resnet_create", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
+    "cough_resnet_create", "cough_resnet_create_ex", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
@@ -101,6 +101,8 @@ def load() -> C.CDLL:
         lib.cough_featurizer_workspace_bytes.restype = C.c_size_t
         lib.cough_featurize_ws.argtypes = [vp, vp, ll, vp, i, i, vp, C.c_size_t, vp]
         lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
+        lib.cough_resnet_create_ex.argtypes = [C.POINTER(vp), i, C.POINTER(i), C.POINTER(ConvBN), C.POINTER(ResBlockWeights),
+                                               _FP, _FP, C.c_float, i]
         lib.cough_resnet_destroy.argtypes = [vp]
         lib.cough_resnet_destroy.restype = None
         lib.cough_resnet_workspace_bytes.argtypes = [vp, i, i, i]

@@ -60,16 +60,18 @@ constexpr int STEM_K = 49, STEM_KS = 25, STEM_N = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w,
                                                         long long n_pool /* B*P1h*P1w */,
-                                                        const float* __restrict__ wk /* [50][32] */,
-                                                        const float* __restrict__ bias, T* __restrict__ out) {
+                                                        const float* __restrict__ wk /* [50][N] */,
+                                                        const float* __restrict__ bias, T* __restrict__ out,
+                                                        int N /* output channels, multiple of 32; blockIdx.y = 32-channel tile */) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 32;
     const long long n_tiles = (n_pool + 7) / 8;
     const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     float bw[STEM_KS];
 #pragma unroll
-    for (int ks = 0; ks < STEM_KS; ++ks) bw[ks] = wk[(2 * ks + h) * STEM_N + r];
-    const float bn = bias[r];
+    for (int ks = 0; ks < STEM_KS; ++ks) bw[ks] = wk[(2 * ks + h) * N + n0 + r];
+    const float bn = bias[n0 + r];
     const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
     const int per_clip = P1h * P1w;
     for (long long tile = wave_id; tile < n_tiles; tile += n_waves) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             const long long Po = tile * 8 + 2 * g + h;
             float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bn;
             v = fmaxf(v, 0.f);
-            if (Po < n_pool) out[Po * STEM_N + r] = from_f32<T>(v);
+            if (Po < n_pool) out[Po * N + n0 + r] = from_f32<T>(v);
         }
     }
 }
@@ -268,9 +270,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16{0};
 
+    const int n_base = blockIdx.y * 32 * NT;   // blockIdx.y: slice of 32 * NT output channels (0 for the shipped 64 / 128)
     const T* wrow[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.wp + (long long)(nt * 32 + r) * a.Ktot;
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.wp + (long long)(n_base + nt * 32 + r) * a.Ktot;
 
     int kbase = 0;
     for (int kh = 0; kh < a.KH; ++kh)
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs<T> a) {
     // epilogue: + folded bias, ReLU, NHWC store (lane = channel -> 32 consecutive channels per row)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = nt * 32 + r;
+        const int n = n_base + nt * 32 + r;
         const float bn = a.bias[n];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -736,6 +739,52 @@ __global__ __launch_bounds__(128) void tail_kernel(const T* __restrict__ a3, int
     }
 }
 
+// Head for any channel count (CoughDetectorResidual(channels=...) other than the shipped tuple): C real channels at
+// stride Cp (channels are padded to a multiple of 32 in memory), one workgroup per clip.
+__global__ __launch_bounds__(128) void tail_generic_kernel(const float* __restrict__ a, int HW, int C, int Cp,
+                                                           const float* __restrict__ fcw /* [2][C] */,
+                                                           const float* __restrict__ fcb, float* __restrict__ logits,
+                                                           float* __restrict__ probs, int* __restrict__ preds) {
+    __shared__ float red[2][2];
+    const long long b = blockIdx.x;
+    const float* p = a + b * (long long)HW * Cp;
+    float l0 = 0.f, l1 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 128) {
+        float s = 0.f;
+        for (int i = 0; i < HW; ++i) s += p[(long long)i * Cp + c];
+        const float mean = s / float(HW);
+        l0 += mean * fcw[c];
+        l1 += mean * fcw[C + c];
+    }
+    l0 = wave_sum(l0);
+    l1 = wave_sum(l1);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = l0; red[threadIdx.x >> 6][1] = l1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        l0 = red[0][0] + red[1][0] + fcb[0];
+        l1 = red[0][1] + red[1][1] + fcb[1];
+        logits[b * 2] = l0;
+        logits[b * 2 + 1] = l1;
+        if (probs) {
+            const float mx = fmaxf(l0, l1), e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.0f / (e0 + e1);
+            probs[b * 2] = e0 * inv;
+            probs[b * 2 + 1] = e1 * inv;
+        }
+        if (preds) preds[b] = (l1 > l0) ? 1 : 0;
+    }
+}
+
+__global__ void nhwc_padded_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int Cp, int HW,
+                                           long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int hw = int(idx % HW);
+    const long long t = idx / HW;
+    const int c = int(t % C);
+    const long long b = t / C;
+    out[idx] = in[(b * HW + hw) * Cp + c];
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,6 +840,19 @@ struct cough_resnet {
     int ktot[4];
     float* d_fcw;          // [2][128]
     float* d_fcb;
+    struct cough_resnet_generic* gen;   // channels other than (32, 64, 128): exact-f32 kernels over padded channels
+};
+
+// CoughDetectorResidual(channels=(c0, ..., cn)) for any tuple (model.py:216-247): channel counts are padded to
+// multiples of 32 with zero weights / biases (a padded channel is ReLU(0) = 0 everywhere), the kernels are the f32
+// MFMA kernels of the shipped net with the output channels tiled over blockIdx.y.
+struct cough_resnet_generic {
+    int n_blocks;
+    std::vector<int> ch, chp;          // real / padded channels, n_blocks + 1 entries
+    float *d_stem_w, *d_stem_b;        // [50][chp0], [chp0]
+    std::vector<float*> d_w, d_b;      // per block: conv1 [N][9*Cin], conv2 + skip [N][9*N + Cin] (padded sizes), biases
+    std::vector<int> ktot;
+    float *d_fcw, *d_fcb;              // [2][c_last], [2]
 };
 
 namespace cough {
@@ -861,6 +923,97 @@ Workspace carve(const cough_resnet* m, char* base, int n, const Shapes& s) {
     return w;
 }
 
+// ------------------------------------------------------------------------------ generic channel tuples (f32)
+struct GenShape { int h, w; };
+// spatial sizes: [0] after the stem + pool, [i + 1] after block i
+std::vector<GenShape> gen_shapes(const cough_resnet_generic* g, int H, int W) {
+    std::vector<GenShape> v;
+    const int c1h = (H + 6 - 7) / 2 + 1, c1w = (W + 6 - 7) / 2 + 1;
+    v.push_back({c1h / 2, c1w / 2});
+    for (int i = 0; i < g->n_blocks; ++i) v.push_back({(v.back().h + 2 - 3) / 2 + 1, (v.back().w + 2 - 3) / 2 + 1});
+    return v;
+}
+// workspace: a[0] (stem out), then per block h[i] and a[i + 1]; NHWC f32 with padded channels
+struct GenWorkspace {
+    std::vector<float*> a, h;
+    size_t total;
+};
+GenWorkspace gen_carve(const cough_resnet_generic* g, char* base, int n, const std::vector<GenShape>& sh) {
+    GenWorkspace w;
+    size_t off = 0;
+    auto take = [&](size_t elems) { float* p = reinterpret_cast<float*>(base + off); off += align256(elems * 4); return p; };
+    w.a.push_back(take(size_t(n) * sh[0].h * sh[0].w * g->chp[0]));
+    for (int i = 0; i < g->n_blocks; ++i) {
+        w.h.push_back(take(size_t(n) * sh[i + 1].h * sh[i + 1].w * g->chp[i + 1]));
+        w.a.push_back(take(size_t(n) * sh[i + 1].h * sh[i + 1].w * g->chp[i + 1]));
+    }
+    w.total = off;
+    return w;
+}
+
+int gen_forward(const cough_resnet_generic* g, const float* d_feat, int n, int H, int W, float* d_logits, float* d_probs,
+                int* d_preds, char* ws, hipStream_t st) {
+    const std::vector<GenShape> sh = gen_shapes(g, H, W);
+    const GenWorkspace w = gen_carve(g, ws, n, sh);
+    {   // stem
+        const long long n_pool = (long long)n * sh[0].h * sh[0].w;
+        const long long tiles = (n_pool + 7) / 8;
+        long long blocks = (tiles + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(stem_mfma_kernel<float>, dim3((unsigned)blocks, g->chp[0] / 32), dim3(256), 0, st, d_feat, H, W,
+                           sh[0].h, sh[0].w, n_pool, g->d_stem_w, g->d_stem_b, w.a[0], g->chp[0]);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    for (int i = 0; i < g->n_blocks; ++i) {
+        const int cin = g->chp[i], cout = g->chp[i + 1];
+        const long long M = (long long)n * sh[i + 1].h * sh[i + 1].w;
+        const int xh = i == 0 ? sh[0].h : sh[i].h, xw = i == 0 ? sh[0].w : sh[i].w;
+        ConvArgs<float> c1{};
+        c1.in = w.a[i]; c1.H = xh; c1.W = xw; c1.C = cin; c1.KH = 3; c1.KW = 3; c1.stride = 2; c1.pad = 1;
+        c1.in2 = nullptr; c1.C2 = 0; c1.H2 = c1.W2 = 0; c1.stride2 = 1;
+        c1.wp = g->d_w[2 * i]; c1.bias = g->d_b[2 * i]; c1.out = w.h[i];
+        c1.OH = sh[i + 1].h; c1.OW = sh[i + 1].w; c1.N = cout; c1.Ktot = g->ktot[2 * i]; c1.M = M;
+        ConvArgs<float> c2{};
+        c2.in = w.h[i]; c2.H = sh[i + 1].h; c2.W = sh[i + 1].w; c2.C = cout; c2.KH = 3; c2.KW = 3; c2.stride = 1; c2.pad = 1;
+        c2.in2 = w.a[i]; c2.H2 = xh; c2.W2 = xw; c2.C2 = cin; c2.stride2 = 2;
+        c2.wp = g->d_w[2 * i + 1]; c2.bias = g->d_b[2 * i + 1]; c2.out = w.a[i + 1];
+        c2.OH = sh[i + 1].h; c2.OW = sh[i + 1].w; c2.N = cout; c2.Ktot = g->ktot[2 * i + 1]; c2.M = M;
+        const long long tiles = (M + 31) / 32;
+        const dim3 grid((unsigned)((tiles + 3) / 4), cout / 32);
+        if (M > 0) {
+            hipLaunchKernelGGL((conv_mfma_kernel<float, 1>), grid, dim3(256), 0, st, c1);
+            hipLaunchKernelGGL((conv_mfma_kernel<float, 1>), grid, dim3(256), 0, st, c2);
+            COUGH_HIP_CHECK(hipGetLastError());
+        }
+    }
+    const int L = g->n_blocks;
+    hipLaunchKernelGGL(tail_generic_kernel, dim3(n), dim3(128), 0, st, w.a[L], sh[L].h * sh[L].w, g->ch[L], g->chp[L],
+                       g->d_fcw, g->d_fcb, d_logits, d_probs, d_preds);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+void gen_destroy(cough_resnet_generic* g) {
+    if (!g) return;
+    (void)hipFree(g->d_stem_w);
+    (void)hipFree(g->d_stem_b);
+    for (float* p : g->d_w) (void)hipFree(p);
+    for (float* p : g->d_b) (void)hipFree(p);
+    (void)hipFree(g->d_fcw);
+    (void)hipFree(g->d_fcb);
+    delete g;
+}
+
+// BN-folded [N][K] weights re-laid for padded channel counts: k = (kh*KW + kw)*Cp + c, zero for padded n / c
+void pad_folded(const FoldedConv& f, int Np, int Cp, std::vector<float>& w, int koff, int K, std::vector<float>& b, bool add_bias) {
+    for (int n = 0; n < f.N; ++n) {
+        for (int t = 0; t < f.KH * f.KW; ++t)
+            for (int c = 0; c < f.C; ++c) w[size_t(n) * K + koff + t * Cp + c] = f.w[size_t(n) * f.KH * f.KW * f.C + t * f.C + c];
+        b[n] = (add_bias ? b[n] : 0.f) + f.b[n];
+    }
+    (void)Np;
+}
+
 template <typename T>
 int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     if (a.M == 0) return COUGH_OK;
@@ -908,7 +1061,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
         long long blocks = (tiles + 3) / 4;
         if (blocks > 256 * 8) blocks = 256 * 8;   // grid-stride over tiles: weights stay in registers
         hipLaunchKernelGGL(stem_mfma_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, d_feat, s.H, s.W, s.P1h,
-                           s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
+                           s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1), STEM_N);
     }
     COUGH_HIP_CHECK(hipGetLastError());
 
@@ -1104,8 +1257,75 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
     return COUGH_OK;
 }
 
+extern "C" int cough_resnet_create_ex(cough_resnet** out, int n_blocks, const int* channels, const cough_conv_bn* stem,
+                                      const cough_resblock_weights* blocks, const float* fc_w, const float* fc_b,
+                                      float bn_eps, int dtype) {
+    using namespace cough;
+    COUGH_REQUIRE(out && channels && stem && blocks && fc_w && fc_b, COUGH_EINVAL, "cough_resnet_create_ex: NULL argument");
+    COUGH_REQUIRE(n_blocks >= 1 && n_blocks <= 16, COUGH_EINVAL, "cough_resnet_create_ex: n_blocks must be 1..16");
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_BF16X3, COUGH_EINVAL,
+                  "cough_resnet_create_ex: unknown dtype %d", dtype);
+    for (int i = 0; i <= n_blocks; ++i)
+        COUGH_REQUIRE(channels[i] >= 1 && channels[i] <= 1024, COUGH_EINVAL, "cough_resnet_create_ex: channels[%d] = %d", i, channels[i]);
+    cough_resnet* m = new cough_resnet();
+    std::memset(m, 0, sizeof(*m));
+    m->dtype = COUGH_DTYPE_FP32;   // every dtype runs a non-shipped channel tuple on the exact-f32 kernels
+    m->esize = 4;
+    cough_resnet_generic* g = new cough_resnet_generic();
+    g->n_blocks = n_blocks;
+    g->d_stem_w = g->d_stem_b = g->d_fcw = g->d_fcb = nullptr;
+    for (int i = 0; i <= n_blocks; ++i) {
+        g->ch.push_back(channels[i]);
+        g->chp.push_back((channels[i] + 31) / 32 * 32);
+    }
+    m->gen = g;
+    int err = COUGH_OK;
+    {
+        const FoldedConv f = fold(*stem, g->ch[0], 1, 7, 7, bn_eps);
+        const int Np = g->chp[0];
+        std::vector<float> wk(size_t(50) * Np, 0.f), b(Np, 0.f);
+        for (int n = 0; n < g->ch[0]; ++n) {
+            for (int k = 0; k < 49; ++k) wk[size_t(k) * Np + n] = f.w[size_t(n) * 49 + k];
+            b[n] = f.b[n];
+        }
+        err = upload(reinterpret_cast<void**>(&g->d_stem_w), wk);
+        if (!err) err = upload(reinterpret_cast<void**>(&g->d_stem_b), b);
+    }
+    for (int i = 0; i < n_blocks && !err; ++i) {
+        const int ci = g->ch[i], co = g->ch[i + 1], cip = g->chp[i], cop = g->chp[i + 1];
+        const FoldedConv c1 = fold(blocks[i].conv1, co, ci, 3, 3, bn_eps);
+        const FoldedConv c2 = fold(blocks[i].conv2, co, co, 3, 3, bn_eps);
+        const FoldedConv sk = fold(blocks[i].skip, co, ci, 1, 1, bn_eps);
+        const int K1 = 9 * cip, K2 = 9 * cop + cip;
+        std::vector<float> w1(size_t(cop) * K1, 0.f), b1(cop, 0.f), w2(size_t(cop) * K2, 0.f), b2(cop, 0.f);
+        pad_folded(c1, cop, cip, w1, 0, K1, b1, false);
+        pad_folded(c2, cop, cop, w2, 0, K2, b2, false);
+        pad_folded(sk, cop, cip, w2, 9 * cop, K2, b2, true);
+        float *dw1 = nullptr, *dw2 = nullptr, *db1 = nullptr, *db2 = nullptr;
+        err = upload(reinterpret_cast<void**>(&dw1), w1);
+        if (!err) err = upload(reinterpret_cast<void**>(&db1), b1);
+        if (!err) err = upload(reinterpret_cast<void**>(&dw2), w2);
+        if (!err) err = upload(reinterpret_cast<void**>(&db2), b2);
+        g->d_w.push_back(dw1); g->d_w.push_back(dw2);
+        g->d_b.push_back(db1); g->d_b.push_back(db2);
+        g->ktot.push_back(K1); g->ktot.push_back(K2);
+    }
+    if (!err) {
+        std::vector<float> fw(fc_w, fc_w + 2 * size_t(g->ch[n_blocks])), fb(fc_b, fc_b + 2);
+        err = upload(reinterpret_cast<void**>(&g->d_fcw), fw);
+        if (!err) err = upload(reinterpret_cast<void**>(&g->d_fcb), fb);
+    }
+    if (err) {
+        cough_resnet_destroy(m);
+        return err;
+    }
+    *out = m;
+    return COUGH_OK;
+}
+
 extern "C" void cough_resnet_destroy(cough_resnet* m) {
     if (!m) return;
+    cough::gen_destroy(m->gen);
     (void)hipFree(m->d_stem_w);
     (void)hipFree(m->d_stem_wfrag);
     (void)hipFree(m->d_stem_b);
@@ -1126,6 +1346,7 @@ extern "C" void cough_resnet_destroy(cough_resnet* m) {
 extern "C" size_t cough_resnet_workspace_bytes(const cough_resnet* m, int n_clips, int height, int width) {
     using namespace cough;
     if (!m || n_clips < 0 || height < 1 || width < 1) return 0;
+    if (m->gen) return gen_carve(m->gen, nullptr, n_clips, gen_shapes(m->gen, height, width)).total;
     return carve(m, nullptr, n_clips, make_shapes(height, width)).total;
 }
 
@@ -1136,6 +1357,11 @@ extern "C" int cough_resnet_forward(const cough_resnet* m, const float* d_feat, 
     COUGH_REQUIRE(m && d_feat && d_logits && d_workspace, COUGH_EINVAL, "cough_resnet_forward: NULL argument");
     COUGH_REQUIRE(n_clips >= 0 && height >= 1 && width >= 1, COUGH_EINVAL, "cough_resnet_forward: bad shape");
     const Shapes s = make_shapes(height, width);
+    if (m->gen) {
+        const std::vector<GenShape> sh = gen_shapes(m->gen, height, width);
+        COUGH_REQUIRE(sh.back().h >= 1 && sh.back().w >= 1 && sh[0].h >= 1 && sh[0].w >= 1, COUGH_EINVAL,
+                      "cough_resnet_forward: input %dx%d too small for the network", height, width);
+    } else
     COUGH_REQUIRE(s.B1h >= 1 && s.B1w >= 1 && s.P1h >= 1 && s.P1w >= 1, COUGH_EINVAL,
                   "cough_resnet_forward: input %dx%d too small for the network", height, width);
     COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL,
@@ -1145,6 +1371,7 @@ extern "C" int cough_resnet_forward(const cough_resnet* m, const float* d_feat, 
     if (n_clips == 0) return COUGH_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(d_workspace);
+    if (m->gen) return gen_forward(m->gen, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st);
     if (m->esize == 4) return forward_impl<float>(m, d_feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
     return forward_impl<bf16_t>(m, d_feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
 }
@@ -1153,6 +1380,20 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
                                             int width, int which, float* d_out, void* stream) {
     using namespace cough;
     COUGH_REQUIRE(m && d_workspace && d_out, COUGH_EINVAL, "cough_resnet_read_activation: NULL argument");
+    if (m->gen) {
+        const cough_resnet_generic* g = m->gen;
+        COUGH_REQUIRE(which >= 1 && which <= g->n_blocks + 1, COUGH_EINVAL, "cough_resnet_read_activation: which must be 1..%d",
+                      g->n_blocks + 1);
+        const std::vector<GenShape> sh = gen_shapes(g, height, width);
+        const GenWorkspace gw = gen_carve(g, const_cast<char*>(static_cast<const char*>(d_workspace)), n_clips, sh);
+        const int C = g->ch[which - 1], Cp = g->chp[which - 1], HW = sh[which - 1].h * sh[which - 1].w;
+        const long long total = (long long)n_clips * C * HW;
+        if (total == 0) return COUGH_OK;
+        hipLaunchKernelGGL(nhwc_padded_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), gw.a[which - 1], d_out, C, Cp, HW, total);
+        COUGH_HIP_CHECK(hipGetLastError());
+        return COUGH_OK;
+    }
     COUGH_REQUIRE(which >= 1 && which <= 3, COUGH_EINVAL, "cough_resnet_read_activation: which must be 1..3");
     const Shapes s = make_shapes(height, width);
     const Workspace w = carve(m, const_cast<char*>(static_cast<const char*>(d_workspace)), n_clips, s);
@@ -1177,7 +1418,7 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
 namespace cough {
 namespace {
 bool can_fuse_stem(const cough_featurizer* f, const cough_resnet* m) {
-    return (m->dtype == COUGH_DTYPE_BF16 || m->dtype == COUGH_DTYPE_BF16X3) && featurizer_stem_fusable(f) &&
+    return !m->gen && (m->dtype == COUGH_DTYPE_BF16 || m->dtype == COUGH_DTYPE_BF16X3) && featurizer_stem_fusable(f) &&
            cough_featurizer_num_frames(f) == 101;
 }
 }  // namespace
@@ -1224,6 +1465,7 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
                                  featurizer_workspace_bytes(f, n_clips)))
         return e;
     if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
+    if (m->gen) return gen_forward(m->gen, feat, n_clips, H, W, d_logits, d_probs, d_preds, ws, st);
     if (m->esize == 4) return forward_impl<float>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
     return forward_impl<bf16_t>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
 }

@@ -25,9 +25,10 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
         super().__init__()
-        if stride != 2 or in_channels == out_channels:
-            raise ValueError("ResidualBlock: the MI355X path implements the projection block (stride 2, "
-                             "in_channels != out_channels) used by CoughDetectorResidual")
+        if stride != 2:
+            raise ValueError("ResidualBlock: the MI355X path implements the stride-2 projection block that "
+                             "CoughDetectorResidual builds (src/model.py:249-251); the stride-1 identity-skip form is "
+                             "never instantiated by the reference")
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=stride, padding=1)
         self.bn1 = nn.BatchNorm2d(out_channels)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
@@ -57,9 +58,12 @@ class CoughDetectorResidual(nn.Module):
     def __init__(self, n_mels: int = 64, num_classes: int = 2, in_channels: int = 1,
                  channels: Tuple[int, ...] = (32, 64, 128), dropout: float = 0.5, compute_dtype: str = "fp32"):
         super().__init__()
-        if num_classes != 2 or in_channels != 1 or tuple(channels) != (32, 64, 128):
-            raise ValueError("CoughDetectorResidual: the MI355X path implements num_classes=2, in_channels=1, "
-                             "channels=(32, 64, 128)")
+        channels = tuple(int(c) for c in channels)
+        if num_classes != 2 or in_channels != 1:
+            raise ValueError("CoughDetectorResidual: the MI355X path implements num_classes=2, in_channels=1")
+        if len(channels) < 2 or len(channels) > 17 or any(c < 1 or c > 1024 for c in channels):
+            raise ValueError("CoughDetectorResidual: channels must be 2..17 values in 1..1024")
+        self.channels = channels          # (32, 64, 128): the fused kernels; any other tuple: the exact-f32 kernels
         if compute_dtype not in ("fp32", "bf16", "bf16x3", "_direct"):
             raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
         self.compute_dtype = compute_dtype
@@ -121,19 +125,34 @@ class CoughDetectorResidual(nn.Module):
                                _lib.fptr(sd[bn + ".weight"]), _lib.fptr(sd[bn + ".bias"]),
                                _lib.fptr(sd[bn + ".running_mean"]), _lib.fptr(sd[bn + ".running_var"]))
 
-        w = _lib.ResNetWeights()
-        w.stem = cb("conv1.0", "conv1.1")
-        for i in range(2):
-            p = f"res_blocks.{i}"
-            w.block[i].conv1 = cb(p + ".conv1", p + ".bn1")
-            w.block[i].conv2 = cb(p + ".conv2", p + ".bn2")
-            w.block[i].skip = cb(p + ".skip.0", p + ".skip.1")
-        w.fc_w = _lib.fptr(sd["fc.2.weight"])
-        w.fc_b = _lib.fptr(sd["fc.2.bias"])
-        w.bn_eps = float(self.conv1[1].eps)
         h = C.c_void_p()
-        _lib.check(lib.cough_resnet_create(C.byref(h), C.byref(w), _lib.DTYPES[self.compute_dtype]),
-                   "cough_resnet_create")
+        if self.channels == (32, 64, 128):
+            w = _lib.ResNetWeights()
+            w.stem = cb("conv1.0", "conv1.1")
+            for i in range(2):
+                p = f"res_blocks.{i}"
+                w.block[i].conv1 = cb(p + ".conv1", p + ".bn1")
+                w.block[i].conv2 = cb(p + ".conv2", p + ".bn2")
+                w.block[i].skip = cb(p + ".skip.0", p + ".skip.1")
+            w.fc_w = _lib.fptr(sd["fc.2.weight"])
+            w.fc_b = _lib.fptr(sd["fc.2.bias"])
+            w.bn_eps = float(self.conv1[1].eps)
+            _lib.check(lib.cough_resnet_create(C.byref(h), C.byref(w), _lib.DTYPES[self.compute_dtype]),
+                       "cough_resnet_create")
+        else:                                  # any other channel tuple (src/model.py:216-247): exact-f32 kernels
+            nb = len(self.channels) - 1
+            blocks = (_lib.ResBlockWeights * nb)()
+            for i in range(nb):
+                p = f"res_blocks.{i}"
+                blocks[i].conv1 = cb(p + ".conv1", p + ".bn1")
+                blocks[i].conv2 = cb(p + ".conv2", p + ".bn2")
+                blocks[i].skip = cb(p + ".skip.0", p + ".skip.1")
+            stem = cb("conv1.0", "conv1.1")
+            chans = (C.c_int * (nb + 1))(*self.channels)
+            dtype = _lib.DTYPES["fp32" if self.compute_dtype == "_direct" else self.compute_dtype]
+            _lib.check(lib.cough_resnet_create_ex(C.byref(h), nb, chans, C.byref(stem), blocks, _lib.fptr(sd["fc.2.weight"]),
+                                                  _lib.fptr(sd["fc.2.bias"]), float(self.conv1[1].eps), dtype),
+                       "cough_resnet_create_ex")
         self._handle, self._handle_key = h, key
         return h
 
@@ -178,13 +197,14 @@ class CoughDetectorResidual(nn.Module):
         return preds.to(torch.int64), probs
 
     def read_activation(self, which: int) -> torch.Tensor:
-        """Parity tap: activation after the stem (1), block 0 (2) or block 1 (3) of the last forward, NCHW f32."""
+        """Parity tap: activation after the stem (1), block 0 (2), block 1 (3), ... of the last forward, NCHW f32."""
         b, hgt, wid = self._last_shape
-        c = {1: 32, 2: 64, 3: 128}[which]
-        h1, w1 = ((hgt - 1) // 2 + 1) // 2, ((wid - 1) // 2 + 1) // 2
-        h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
-        h3, w3 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
-        oh, ow = {1: (h1, w1), 2: (h2, w2), 3: (h3, w3)}[which]
+        if not 1 <= which <= len(self.channels):
+            raise ValueError(f"which must be 1..{len(self.channels)}")
+        c = self.channels[which - 1]
+        oh, ow = ((hgt - 1) // 2 + 1) // 2, ((wid - 1) // 2 + 1) // 2
+        for _ in range(which - 1):
+            oh, ow = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
         out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=self._workspace.device)
         stream = torch.cuda.current_stream(out.device).cuda_stream
         _lib.check(_lib.load().cough_resnet_read_activation(self._native(), self._workspace.data_ptr(), b, hgt, wid,

@@ -185,7 +185,7 @@ def make_stream(seed: int, seconds: float) -> np.ndarray:
     return np.concatenate(parts)[:n]
 
 
-def random_state_dict(seed: int = 0) -> dict:
+def random_state_dict(seed: int = 0, channels=(32, 64, 128)) -> dict:
     """Random-init classifier weights with the reference's state_dict key set / shapes
     (``/root/reference/src/model.py:216-283``) and NON-trivial BatchNorm statistics (fresh-init 0/1
     stats would not exercise BN folding).  No checkpoint is available offline."""
@@ -204,10 +204,10 @@ def random_state_dict(seed: int = 0) -> dict:
         sd[name + ".running_var"] = torch.rand(c, generator=g) * 1.5 + 0.25
         sd[name + ".num_batches_tracked"] = torch.tensor(100)
 
-    conv("conv1.0", 32, 1, 7)
-    bn("conv1.1", 32)
-    ci = 32
-    for i, co in enumerate((64, 128)):
+    conv("conv1.0", channels[0], 1, 7)
+    bn("conv1.1", channels[0])
+    ci = channels[0]
+    for i, co in enumerate(channels[1:]):
         p = f"res_blocks.{i}"
         conv(p + ".conv1", co, ci, 3)
         bn(p + ".bn1", co)
@@ -216,6 +216,6 @@ def random_state_dict(seed: int = 0) -> dict:
         conv(p + ".skip.0", co, ci, 1)
         bn(p + ".skip.1", co)
         ci = co
-    sd["fc.2.weight"] = (torch.rand(2, 128, generator=g) * 2 - 1) / 128 ** 0.5
-    sd["fc.2.bias"] = (torch.rand(2, generator=g) * 2 - 1) / 128 ** 0.5
+    sd["fc.2.weight"] = (torch.rand(2, ci, generator=g) * 2 - 1) / ci ** 0.5
+    sd["fc.2.bias"] = (torch.rand(2, generator=g) * 2 - 1) / ci ** 0.5
     return sd

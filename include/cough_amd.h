@@ -144,6 +144,13 @@ typedef struct cough_resnet_weights {
 typedef struct cough_resnet cough_resnet;
 
 int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype);
+/* The same for any `channels` tuple of CoughDetectorResidual.__init__ (/root/reference/src/model.py:216-247):
+ * channels[0 .. n_blocks] = (stem out, block 0 out, ..., block n_blocks-1 out); blocks[i] holds res_blocks.i;
+ * fc_w is fc.2.weight [2][channels[n_blocks]].  Tuples other than (32, 64, 128) run on the exact-f32 kernels
+ * whatever `dtype` asks for (channel counts padded to multiples of 32 in device memory). */
+int cough_resnet_create_ex(cough_resnet** out, int n_blocks, const int* channels, const cough_conv_bn* stem,
+                           const cough_resblock_weights* blocks, const float* fc_w, const float* fc_b, float bn_eps,
+                           int dtype);
 void cough_resnet_destroy(cough_resnet* m);
 size_t cough_resnet_workspace_bytes(const cough_resnet* m, int n_clips, int height, int width);
 
@@ -154,7 +161,7 @@ int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips
                          float* d_logits, float* d_probs, int* d_preds,
                          void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Parity taps: copy the activation after the stem (which=1), block 0 (2) or block 1 (3) of the
+/* Parity taps: copy the activation after the stem (which=1), block 0 (2), block 1 (3), ... of the
  * LAST forward on this workspace to d_out as [n_clips][C][H][W] float32. */
 int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips,
                                  int height, int width, int which, float* d_out, void* stream);

@@ -43,12 +43,15 @@ def head(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
 
 
 def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], return_intermediates: bool = False):
-    a1 = stem(x, sd)
-    a2 = res_block(a1, sd, 0)
-    a3 = res_block(a2, sd, 1)
-    logits = head(a3, sd)
+    """Any ``channels`` tuple (model.py:216-247): one block per ``res_blocks.i`` found in the state_dict."""
+    acts = [stem(x, sd)]
+    i = 0
+    while f"res_blocks.{i}.conv1.weight" in sd:
+        acts.append(res_block(acts[-1], sd, i))
+        i += 1
+    logits = head(acts[-1], sd)
     if return_intermediates:
-        return logits, (a1, a2, a3)
+        return logits, tuple(acts)
     return logits
 
 

@@ -41,6 +41,26 @@ def resnet_golden():
 
 
 @pytest.fixture(scope="session")
+def resnet_channels_golden():
+    """{case: (channels, state_dict, vectors)} for non-default ``channels`` tuples (oracle/make_golden_channels.py);
+    the inputs are the first clips of features_golden.npz."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(GOLDEN, "resnet_channels_golden.npz"))
+    n = int(g["n_clips"])
+    x = torch.from_numpy(np.load(os.path.join(GOLDEN, "features_golden.npz"))["features"][:n]).unsqueeze(1).contiguous()
+    cases = {}
+    for name in sorted({k.split(".")[0] for k in g.files if "." in k}):
+        pre = name + ".sd."
+        sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+        vec = {k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files
+               if k.startswith(name + ".") and not k.startswith(pre)}
+        vec["x"] = x
+        cases[name] = (tuple(int(c) for c in vec.pop("channels")), sd, vec)
+    return cases
+
+
+@pytest.fixture(scope="session")
 def features_golden():
     import numpy as np
     g = np.load(os.path.join(GOLDEN, "features_golden.npz"))
