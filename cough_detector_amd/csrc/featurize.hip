@@ -545,6 +545,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             epilogue(ta, ca, false);
             if (last) epilogue(ST_TILES - 1, cb, true);
         }
+        K1_STAMP(7);   // stem done (wave 0)
     }
 }
 

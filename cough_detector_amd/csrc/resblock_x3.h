@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     const int nvalid = a.n_clips - clip0 < G ? a.n_clips - clip0 : G;
     RB_STAMP(0);
 
+    // biases first: vector-memory loads return in issue order, so a bias loaded after the staging loads and stored
+    // to LDS straight away would drain every load of wave 0 before its first piece is split
+    float bv1 = 0.f, bv2 = 0.f;
+    if (tid < COUT) { bv1 = a.b1[tid]; bv2 = a.b2[tid]; }
+
     // ---- weight fragment stream (hi, lo per k-step) -------------------------------------------------------
     const bf16_t* wbase = a.wf + size_t(ng) * 1024 + lane * 8;
     auto wfrag = [&](int s, int plane) -> bf16x8 {
@@ -173,11 +178,11 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         float4 v[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+            // unconditional, index-clamped loads: a load under a branch makes the compiler drain vmcnt to 0 before the
+            // first piece is split; clamped, the pieces are processed as they arrive (vmcnt(UN - 1 - u))
             const int i = tid + u * THREADS;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < valid) v[u] = src[i];
+            v[u] = src[i < valid ? i : valid - 1];
         }
-        if (tid < COUT) { lbias[tid] = a.b1[tid]; lbias[COUT + tid] = a.b2[tid]; }
         if (tid < 2 * CHI) {   // the zero cell of every chunk plane, hi and lo
             *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
         }
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 const int cell = g * NPP + ((ih & 1) ? ((iw & 1) ? Cfg::PB11 : Cfg::PB10) : ((iw & 1) ? Cfg::PB01 : 0)) +
                                  (ih >> 1) * OW + (iw >> 1);
                 uint2 hi, lo;
+                if (i >= valid) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // clips beyond the batch read as zeros
                 split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
                 const int off = (q >> 1) * CPX + cell * 16 + (q & 1) * 8;
                 *reinterpret_cast<uint2*>(smem + off) = hi;
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             }
         }
     }
+    if (tid < COUT) { lbias[tid] = bv1; lbias[COUT + tid] = bv2; }
     float fw0 = 0.f, fw1 = 0.f, fb0 = 0.f, fb1 = 0.f;   // fused head (block 1): Linear(128, 2) weights of channel tid & 127
     if constexpr (COUT == 128) {
         if (a.fcw != nullptr) {

@@ -21,10 +21,14 @@ NAMES = ["P0 peak (normalize)", "P1 frames (wave 0)", "P1 wait for slowest wave"
 
 
 def main():
+    global LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [build._hipcc(), *build.FLAGS, "-DCOUGH_K1_STAMPS", "-o", LIB] + \
-          [os.path.join(build.CSRC, s) for s in build.SOURCES]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    if os.environ.get("K1_STAMPS_LIB"):       # prebuilt with -DCOUGH_K1_STAMPS (tools/build_variant.sh)
+        LIB = os.path.abspath(os.environ["K1_STAMPS_LIB"])
+    else:
+        cmd = [build._hipcc(), *build.FLAGS, "-DCOUGH_K1_STAMPS", "-o", LIB] + \
+              [os.path.join(build.CSRC, s) for s in build.SOURCES]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     _lib.LIB_PATH = LIB
     import cough_detector_amd as cda
     lib = _lib.load()
@@ -49,6 +53,24 @@ def main():
             print(f"  {n:32s} median {d[:, i].median():9.0f}  share {100 * d[:, i].median() / total.median():5.1f}%")
         span = st[:, 6].max() - st[:, 0].min()
         print(f"  grid span {span:.0f} ticks; blocks {B}; mean per-block total {total.mean():.0f}")
+    # fused pipeline (featurise + split-bf16 stem in one kernel): slot 7 = end of the stem phase
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(synth.random_state_dict(seed=3))
+    model.cuda().eval()
+    pipe = cda.CoughPipeline(pre, model)
+    stamps = torch.zeros(B * 8, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        pipe(wav)
+    assert lib.cough_debug_set_stamp_buffer(stamps.data_ptr()) == 0
+    pipe(wav)
+    torch.cuda.synchronize()
+    assert lib.cough_debug_set_stamp_buffer(None) == 0
+    st = stamps.view(B, 8).cpu().double()
+    d = st[:, 1:8] - st[:, 0:7]
+    total = st[:, 7] - st[:, 0]
+    print(f"fused featurise + stem (bf16x3): median workgroup lifetime {total.median():.0f}")
+    for i, n in enumerate(NAMES + ["stem: hi/lo image already built; MFMA + pool + store"]):
+        print(f"  {n:52s} median {d[:, i].median():9.0f}  share {100 * d[:, i].median() / total.median():5.1f}%")
 
 
 if __name__ == "__main__":

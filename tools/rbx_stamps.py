@@ -9,11 +9,15 @@ LIB = os.path.join(ROOT, "gpurun_out", "libcough_amd_stamps.so")
 NAMES = ["stage: loads + split + LDS writes", "barrier after staging", "conv1 + projection k-steps", "barrier + h write + barrier",
          "conv2 k-steps", "barrier + output tile + barrier", "global store (+ head)"]
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
-subprocess.run([build._hipcc(), *build.FLAGS, "-DCOUGH_K1_STAMPS", "-o", LIB] + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True, stderr=subprocess.DEVNULL)
+if os.environ.get("RBX_STAMPS_LIB"):      # a library prebuilt with -DCOUGH_K1_STAMPS (+ variant flags), e.g. by tools/build_variant.sh
+    LIB = os.path.abspath(os.environ["RBX_STAMPS_LIB"])
+    print("==", os.path.basename(LIB))
+else:
+    subprocess.run([build._hipcc(), *build.FLAGS, "-DCOUGH_K1_STAMPS", "-o", LIB] + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True, stderr=subprocess.DEVNULL)
 _lib.LIB_PATH = LIB
 import cough_detector_amd as cda
 lib = _lib.load()
-B = 4096
+B = int(os.environ.get("RBX_STAMPS_B", "4096"))
 model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
 model.load_state_dict(synth.random_state_dict(seed=3)); model.cuda()
 x = torch.rand(B, 1, 90, 101, device="cuda")
