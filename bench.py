@@ -190,6 +190,8 @@ def parse_args(argv=None):
     ap.add_argument("--featurize-only", action="store_true", help="time K1 alone (BASELINE configs[1])")
     ap.add_argument("--rotate", type=int, default=3, help="distinct device-resident input batches the steps cycle over")
     ap.add_argument("--prewarm-s", type=float, default=0.6, help="untimed GPU pre-warm before --warmup (seconds)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps per all-gather of logits (one bucketed exchange per this many steps)")
     ap.add_argument("--total-clips", type=int, default=0,
                     help="configs[3]: one pass over a stream of this many distinct clips (all ranks together); "
                          "overrides --steps and --rotate")
@@ -220,10 +222,12 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()        # builds the communicator now (tens of ms): the barriers around the timed region are then
+                              # short, and the GPU does not idle its clocks down just before the first timed step
 
     import cough_detector_amd as cda
     from cough_detector_amd import synth
-    from cough_detector_amd.distributed import gather_logits_finish, gather_logits_start, local_count
+    from cough_detector_amd.distributed import BucketedLogitsGather, local_count
 
     B, W = args.batch, args.warmup
     # rank r owns global clips r, r+N, r+2N, ... (round-robin); clip g is generated on the device from seed g
@@ -251,7 +255,9 @@ def main():
     feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
     pipe = cda.CoughPipeline(pre, model)
     fused = args.dtype in ("bf16", "bf16x3") and not args.featurize_only   # the stem runs inside the featurise kernel
-    gathered = torch.empty((world * B, 2), dtype=torch.float32, device=dev) if dist else None
+    # every rank ends up with every clip's logits: the steps' logits are exchanged in buckets of --gather-every steps,
+    # one all-gather per bucket on RCCL's stream while the next bucket is computed
+    publisher = BucketedLogitsGather(B, args.gather_every, dev) if dist else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
 
@@ -272,22 +278,18 @@ def main():
         logits = pipe(wav, normalize=True, events=(ev[i][0], ev[i][1]) if timed else None)
         if timed:
             ev[i][2].record()
-        if dist:
-            # publish the step's logits: the all-gather of step i runs on RCCL's stream while step i+1 computes;
-            # its un-interleave copy is issued one step later (every exchange is finished inside the timed region)
-            if pending:
-                h, n = pending.pop()
-                gather_logits_finish(h, out=gathered[:n])
-            pending.append((gather_logits_start(logits, n_total=step_total[i % K]), step_total[i % K]))
-            return gathered
+        if dist and not skip_gather:
+            if i % K == 0:
+                publisher.flush()                         # a bucket never spans the end of the stream (ragged last step)
+            publisher.push(logits, step_total[i % K])     # every exchange is finished inside the timed region (drain)
+            return publisher.out
         return logits
 
-    pending = []
+    skip_gather = os.environ.get("COUGH_BENCH_SKIP_GATHER") == "1"   # diagnostic only: ranks and barriers, no exchange
 
     def drain():
-        while pending:
-            h, n = pending.pop()
-            gather_logits_finish(h, out=gathered[:n])
+        if publisher is not None:
+            publisher.drain()
 
     # ---- untimed pre-warm: the same pipeline until the wall clock says --prewarm-s (GPU at sustained clocks) ----
     t_pw = time.perf_counter()
@@ -347,7 +349,8 @@ def main():
             "dtype": "f32" if args.featurize_only else DTYPE_LABEL[args.dtype], "data": "synthetic",
             "prewarm_s": round(prewarm_s, 3),
             "config": {"workload": workload, "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
-                       "collective": "all_gather(logits) per step, overlapped with the next step" if dist else "none",
+                       "collective": (f"all_gather(logits) once per {args.gather_every} steps ({args.gather_every * B * 8} B per rank), "
+                                      "overlapped with the next bucket's compute") if dist else "none",
                        "inputs": (f"{len(batches)} distinct device-resident batches" if args.total_clips > 0 else
                                   f"{max(1, args.rotate)} distinct device-resident batches in rotation "
                                   f"({max(1, args.rotate) * B * 64000 / 2**20:.0f} MiB)") +

@@ -39,6 +39,44 @@ def _worker(rank, world, port, n_total):
         dist.destroy_process_group()
 
 
+def _bucket_worker(rank, world, port, n_total, batch, every):
+    """A sharded stream scored in steps of ``batch`` local clips, published through BucketedLogitsGather: every
+    finished bucket must hold its global clips in order, ragged last bucket included."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx = cdist.local_indices(n_total, rank, world)[:cdist.local_count(n_total, rank, world)]
+        n_steps = (cdist.local_count(n_total, 0, world) + batch - 1) // batch       # steps of the fullest rank
+        pub = cdist.BucketedLogitsGather(batch, every, device="cpu")
+        seen = []
+
+        def collect():
+            if pub.finished > len(seen):             # a bucket was finished: ``out`` holds it in global clip order
+                seen.append(pub.out[:pub.last_n].clone())
+
+        for j in range(n_steps):
+            mine = idx[j * batch:(j + 1) * batch].float()
+            step_total = min(n_total, (j + 1) * batch * world) - j * batch * world
+            pub.push(torch.stack([mine, -mine], dim=1), step_total)
+            collect()
+        pub.flush()
+        collect()
+        pub.drain()
+        collect()
+        got = torch.cat(seen)
+        want = torch.stack([torch.arange(n_total).float(), -torch.arange(n_total).float()], dim=1)
+        assert torch.equal(got, want), (rank, got.shape, want.shape)
+        assert pub.collectives == (n_steps + every - 1) // every
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,batch,every", [(2, 100, 8, 3), (2, 64, 8, 4), (3, 50, 4, 2), (2, 37, 8, 1)])
+def test_bucketed_stream_gather_gloo(world, n_total, batch, every):
+    mp.spawn(_bucket_worker, args=(world, _free_port(), n_total, batch, every), nprocs=world, join=True)
+
+
 @pytest.mark.parametrize("world,n_total", [(2, 64), (2, 37), (3, 10)])
 def test_round_robin_gather_gloo(world, n_total):
     mp.spawn(_worker, args=(world, _free_port(), n_total), nprocs=world, join=True)
