@@ -25,6 +25,8 @@ SYMBOLS = (
     "cough_featurizer_num_frames", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
     "cough_spectrogram",
     "cough_resnet_create", "cough_resnet_create_ex", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
+    "cough_resblock_create", "cough_resblock_destroy", "cough_resblock_workspace_bytes", "cough_resblock_out_shape",
+    "cough_resblock_forward",
     "cough_resnet_forward", "cough_resnet_read_activation",
     "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
@@ -103,6 +105,14 @@ def load() -> C.CDLL:
         lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
         lib.cough_resnet_create_ex.argtypes = [C.POINTER(vp), i, C.POINTER(i), C.POINTER(ConvBN), C.POINTER(ResBlockWeights),
                                                _FP, _FP, C.c_float, i]
+        lib.cough_resblock_create.argtypes = [C.POINTER(vp), i, i, i, C.POINTER(ConvBN), C.POINTER(ConvBN), C.POINTER(ConvBN),
+                                              C.c_float]
+        lib.cough_resblock_destroy.argtypes = [vp]
+        lib.cough_resblock_destroy.restype = None
+        lib.cough_resblock_workspace_bytes.argtypes = [vp, i, i, i]
+        lib.cough_resblock_workspace_bytes.restype = C.c_size_t
+        lib.cough_resblock_out_shape.argtypes = [vp, i, i, C.POINTER(i), C.POINTER(i)]
+        lib.cough_resblock_forward.argtypes = [vp, vp, i, i, i, vp, vp, C.c_size_t, vp]
         lib.cough_resnet_destroy.argtypes = [vp]
         lib.cough_resnet_destroy.restype = None
         lib.cough_resnet_workspace_bytes.argtypes = [vp, i, i, i]

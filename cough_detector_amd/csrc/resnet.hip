@@ -785,6 +785,18 @@ __global__ void nhwc_padded_to_nchw_kernel(const float* __restrict__ in, float* 
     out[idx] = in[(b * HW + hw) * Cp + c];
 }
 
+// (n, C, H, W) f32 -> NHWC with the channel count padded to Cp (zeros), the layout of the exact-f32 conv kernels
+__global__ void nchw_to_nhwc_padded_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int Cp, int HW,
+                                           long long total /* n * HW * Cp */) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % Cp);
+    const long long t = idx / Cp;
+    const int hw = int(t % HW);
+    const long long b = t / HW;
+    out[idx] = c < C ? in[(b * C + c) * HW + hw] : 0.f;
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1468,4 +1480,133 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
     if (m->gen) return gen_forward(m->gen, feat, n_clips, H, W, d_logits, d_probs, d_preds, ws, st);
     if (m->esize == 4) return forward_impl<float>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
     return forward_impl<bf16_t>(m, feat, n_clips, s, d_logits, d_probs, d_preds, ws, st);
+}
+
+// ------------------------------------------------------------------------------ one ResidualBlock on its own
+// ResidualBlock (/root/reference/src/model.py:268-293) as a module of its own: any in / out channel count, stride 1 or
+// 2, projection skip (1x1 conv + BN) or -- stride 1 and in == out -- the identity (:280-283).  Exact-f32 MFMA conv
+// kernels; the skip is the 1x1 operand appended to conv2's K (an identity matrix for the identity skip: x * 1 + 0s is
+// exact in f32).  CoughDetectorResidual never builds the identity form; this entry exists so that the class is a
+// drop-in wherever the reference's is used directly.
+struct cough_resblock {
+    int cin, cout, cinp, coutp, stride;
+    float *d_w1, *d_b1, *d_w2, *d_b2;
+    int k1, k2;
+};
+
+extern "C" int cough_resblock_create(cough_resblock** out, int in_ch, int out_ch, int stride, const cough_conv_bn* conv1,
+                                     const cough_conv_bn* conv2, const cough_conv_bn* skip, float bn_eps) {
+    using namespace cough;
+    COUGH_REQUIRE(out && conv1 && conv2, COUGH_EINVAL, "cough_resblock_create: NULL argument");
+    COUGH_REQUIRE(in_ch >= 1 && in_ch <= 1024 && out_ch >= 1 && out_ch <= 1024, COUGH_EINVAL,
+                  "cough_resblock_create: channels %d -> %d", in_ch, out_ch);
+    COUGH_REQUIRE(stride >= 1 && stride <= 4, COUGH_EINVAL, "cough_resblock_create: stride %d", stride);
+    COUGH_REQUIRE(skip || (stride == 1 && in_ch == out_ch), COUGH_EINVAL,
+                  "cough_resblock_create: the identity skip needs stride 1 and in_ch == out_ch (model.py:280-283)");
+    cough_resblock* m = new cough_resblock();
+    std::memset(m, 0, sizeof(*m));
+    m->cin = in_ch; m->cout = out_ch; m->stride = stride;
+    m->cinp = (in_ch + 31) / 32 * 32;
+    m->coutp = (out_ch + 31) / 32 * 32;
+    const FoldedConv c1 = fold(*conv1, out_ch, in_ch, 3, 3, bn_eps);
+    const FoldedConv c2 = fold(*conv2, out_ch, out_ch, 3, 3, bn_eps);
+    m->k1 = 9 * m->cinp;
+    m->k2 = 9 * m->coutp + m->cinp;
+    std::vector<float> w1(size_t(m->coutp) * m->k1, 0.f), b1(m->coutp, 0.f), w2(size_t(m->coutp) * m->k2, 0.f), b2(m->coutp, 0.f);
+    pad_folded(c1, m->coutp, m->cinp, w1, 0, m->k1, b1, false);
+    pad_folded(c2, m->coutp, m->coutp, w2, 0, m->k2, b2, false);
+    if (skip) {
+        const FoldedConv sk = fold(*skip, out_ch, in_ch, 1, 1, bn_eps);
+        pad_folded(sk, m->coutp, m->cinp, w2, 9 * m->coutp, m->k2, b2, true);
+    } else {
+        for (int n = 0; n < out_ch; ++n) w2[size_t(n) * m->k2 + 9 * m->coutp + n] = 1.0f;   // out += x
+    }
+    int err = upload(reinterpret_cast<void**>(&m->d_w1), w1);
+    if (!err) err = upload(reinterpret_cast<void**>(&m->d_b1), b1);
+    if (!err) err = upload(reinterpret_cast<void**>(&m->d_w2), w2);
+    if (!err) err = upload(reinterpret_cast<void**>(&m->d_b2), b2);
+    if (err) {
+        cough_resblock_destroy(m);
+        return err;
+    }
+    *out = m;
+    return COUGH_OK;
+}
+
+extern "C" void cough_resblock_destroy(cough_resblock* m) {
+    if (!m) return;
+    (void)hipFree(m->d_w1);
+    (void)hipFree(m->d_b1);
+    (void)hipFree(m->d_w2);
+    (void)hipFree(m->d_b2);
+    delete m;
+}
+
+namespace {
+struct RbShapes { int oh, ow; size_t x, h, y, total; };
+RbShapes rb_shapes(const cough_resblock* m, int n, int H, int W) {
+    RbShapes s;
+    s.oh = (H + 2 - 3) / m->stride + 1;
+    s.ow = (W + 2 - 3) / m->stride + 1;
+    s.x = cough::align256(size_t(n) * H * W * m->cinp * 4);
+    s.h = cough::align256(size_t(n) * s.oh * s.ow * m->coutp * 4);
+    s.y = s.h;
+    s.total = s.x + s.h + s.y;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t cough_resblock_workspace_bytes(const cough_resblock* m, int n, int height, int width) {
+    if (!m || n < 0 || height < 1 || width < 1) return 0;
+    return rb_shapes(m, n, height, width).total;
+}
+
+extern "C" int cough_resblock_out_shape(const cough_resblock* m, int height, int width, int* out_h, int* out_w) {
+    COUGH_REQUIRE(m && out_h && out_w && height >= 1 && width >= 1, COUGH_EINVAL, "cough_resblock_out_shape: bad argument");
+    const RbShapes s = rb_shapes(m, 0, height, width);
+    *out_h = s.oh;
+    *out_w = s.ow;
+    return COUGH_OK;
+}
+
+extern "C" int cough_resblock_forward(const cough_resblock* m, const float* d_x, int n, int height, int width, float* d_y,
+                                      void* d_workspace, size_t workspace_bytes, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(m && d_x && d_y && d_workspace, COUGH_EINVAL, "cough_resblock_forward: NULL argument");
+    COUGH_REQUIRE(n >= 0 && height >= 1 && width >= 1, COUGH_EINVAL, "cough_resblock_forward: bad shape");
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL,
+                  "cough_resblock_forward: workspace must be 256-byte aligned");
+    const RbShapes s = rb_shapes(m, n, height, width);
+    COUGH_REQUIRE(workspace_bytes >= s.total, COUGH_EWORKSPACE, "cough_resblock_forward: workspace too small");
+    if (n == 0) return COUGH_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(d_workspace);
+    float* x = reinterpret_cast<float*>(ws);
+    float* h = reinterpret_cast<float*>(ws + s.x);
+    float* y = reinterpret_cast<float*>(ws + s.x + s.h);
+    {
+        const long long total = (long long)n * height * width * m->cinp;
+        hipLaunchKernelGGL(nchw_to_nhwc_padded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x, x, m->cin,
+                           m->cinp, height * width, total);
+    }
+    const long long M = (long long)n * s.oh * s.ow;
+    ConvArgs<float> c1{};
+    c1.in = x; c1.H = height; c1.W = width; c1.C = m->cinp; c1.KH = 3; c1.KW = 3; c1.stride = m->stride; c1.pad = 1;
+    c1.in2 = nullptr; c1.C2 = 0; c1.H2 = c1.W2 = 0; c1.stride2 = 1;
+    c1.wp = m->d_w1; c1.bias = m->d_b1; c1.out = h; c1.OH = s.oh; c1.OW = s.ow; c1.N = m->coutp; c1.Ktot = m->k1; c1.M = M;
+    ConvArgs<float> c2{};
+    c2.in = h; c2.H = s.oh; c2.W = s.ow; c2.C = m->coutp; c2.KH = 3; c2.KW = 3; c2.stride = 1; c2.pad = 1;
+    c2.in2 = x; c2.H2 = height; c2.W2 = width; c2.C2 = m->cinp; c2.stride2 = m->stride;
+    c2.wp = m->d_w2; c2.bias = m->d_b2; c2.out = y; c2.OH = s.oh; c2.OW = s.ow; c2.N = m->coutp; c2.Ktot = m->k2; c2.M = M;
+    const long long tiles = (M + 31) / 32;
+    const dim3 grid((unsigned)((tiles + 3) / 4), m->coutp / 32);
+    hipLaunchKernelGGL((conv_mfma_kernel<float, 1>), grid, dim3(256), 0, st, c1);
+    hipLaunchKernelGGL((conv_mfma_kernel<float, 1>), grid, dim3(256), 0, st, c2);
+    {
+        const long long total = (long long)n * m->cout * s.oh * s.ow;
+        hipLaunchKernelGGL(nhwc_padded_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, d_y, m->cout,
+                           m->coutp, s.oh * s.ow, total);
+    }
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
 }

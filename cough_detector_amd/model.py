@@ -21,23 +21,89 @@ from . import _lib
 
 
 class ResidualBlock(nn.Module):
-    """Parameter layout of the reference block: conv1/bn1 (3x3 s2), conv2/bn2 (3x3 s1), skip (1x1 s2 + BN)."""
+    """The reference block (``src/model.py:268-293``): conv1/bn1 (3x3, stride s), conv2/bn2 (3x3, stride 1) and ``skip`` --
+    a 1x1 stride-s conv + BN when ``stride != 1 or in_channels != out_channels``, ``nn.Identity()`` otherwise (:280-283).
+
+    Inside ``CoughDetectorResidual`` the blocks run fused in the model's own kernels; called on its own
+    (``block(x)``, x (B, in_channels, H, W)) a block runs through ``cough_resblock_forward`` on the exact-f32 MFMA
+    conv kernels, eval-mode BatchNorm folded."""
 
     def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
         super().__init__()
-        if stride != 2:
-            raise ValueError("ResidualBlock: the MI355X path implements the stride-2 projection block that "
-                             "CoughDetectorResidual builds (src/model.py:249-251); the stride-1 identity-skip form is "
-                             "never instantiated by the reference")
+        if not 1 <= int(stride) <= 4 or in_channels < 1 or out_channels < 1:
+            raise ValueError(f"ResidualBlock: in_channels={in_channels}, out_channels={out_channels}, stride={stride}")
+        self.in_channels, self.out_channels, self.stride = int(in_channels), int(out_channels), int(stride)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=stride, padding=1)
         self.bn1 = nn.BatchNorm2d(out_channels)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.bn2 = nn.BatchNorm2d(out_channels)
         self.skip = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, stride=stride),
-                                  nn.BatchNorm2d(out_channels))
+                                  nn.BatchNorm2d(out_channels)) if in_channels != out_channels or stride != 1 else nn.Identity()
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.eval()
 
-    def forward(self, x):
-        raise RuntimeError("ResidualBlock is executed inside CoughDetectorResidual.forward on the MI355X path")
+    def _release(self):
+        h = self.__dict__.get("_handle")
+        self.__dict__["_handle"] = None
+        if h is not None:
+            try:
+                _lib.load().cough_resblock_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _native(self) -> C.c_void_p:
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._release()
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+
+        def cb(conv: str, bn: str) -> _lib.ConvBN:
+            return _lib.ConvBN(_lib.fptr(sd[conv + ".weight"]), _lib.fptr(sd[conv + ".bias"]),
+                               _lib.fptr(sd[bn + ".weight"]), _lib.fptr(sd[bn + ".bias"]),
+                               _lib.fptr(sd[bn + ".running_mean"]), _lib.fptr(sd[bn + ".running_var"]))
+
+        c1, c2 = cb("conv1", "bn1"), cb("conv2", "bn2")
+        sk = cb("skip.0", "skip.1") if isinstance(self.skip, nn.Sequential) else None
+        h = C.c_void_p()
+        _lib.check(_lib.load().cough_resblock_create(C.byref(h), self.in_channels, self.out_channels, self.stride,
+                                                      C.byref(c1), C.byref(c2), C.byref(sk) if sk is not None else None,
+                                                      float(self.bn1.eps)), "cough_resblock_create")
+        self._handle, self._handle_key = h, key
+        return h
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("ResidualBlock on the MI355X path is inference-only: call .eval()")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input (B, {self.in_channels}, H, W), got {tuple(x.shape)}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        src_dev = x.device
+        xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        b, _, hgt, wid = xf.shape
+        lib, h = _lib.load(), self._native()
+        oh, ow = C.c_int(), C.c_int()
+        _lib.check(lib.cough_resblock_out_shape(h, hgt, wid, C.byref(oh), C.byref(ow)), "cough_resblock_out_shape")
+        y = torch.empty((b, self.out_channels, oh.value, ow.value), dtype=torch.float32, device=dev)
+        if b == 0:
+            return y.to(src_dev)
+        need = lib.cough_resblock_workspace_bytes(h, b, hgt, wid)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        _lib.check(lib.cough_resblock_forward(h, xf.data_ptr(), b, hgt, wid, y.data_ptr(), self._workspace.data_ptr(),
+                                              self._workspace.numel(), torch.cuda.current_stream(dev).cuda_stream),
+                   "cough_resblock_forward")
+        return y.to(src_dev)
 
 
 class CoughDetectorResidual(nn.Module):

@@ -166,6 +166,20 @@ int cough_resnet_forward(const cough_resnet* m, const float* d_feat, int n_clips
 int cough_resnet_read_activation(const cough_resnet* m, const void* d_workspace, int n_clips,
                                  int height, int width, int which, float* d_out, void* stream);
 
+/* One ResidualBlock as a module of its own (/root/reference/src/model.py:268-293):
+ *     y = ReLU( BN2(conv2( ReLU(BN1(conv1(x))) )) + skip(x) ),   conv1 3x3 stride s pad 1, conv2 3x3 stride 1 pad 1,
+ * skip = 1x1 stride-s conv + BN (`skip` != NULL; what ResidualBlock builds when s != 1 or in_ch != out_ch, :280-283) or
+ * the identity (`skip` == NULL: needs s == 1 and in_ch == out_ch).  d_x: [n][in_ch][H][W] f32, d_y: [n][out_ch][OH][OW]
+ * f32 with OH = (H - 1) / s + 1, OW = (W - 1) / s + 1.  Exact-f32 MFMA kernels, eval-mode BatchNorm folded at create. */
+typedef struct cough_resblock cough_resblock;
+int cough_resblock_create(cough_resblock** out, int in_ch, int out_ch, int stride, const cough_conv_bn* conv1,
+                          const cough_conv_bn* conv2, const cough_conv_bn* skip, float bn_eps);
+void cough_resblock_destroy(cough_resblock* m);
+size_t cough_resblock_workspace_bytes(const cough_resblock* m, int n, int height, int width);
+int cough_resblock_out_shape(const cough_resblock* m, int height, int width, int* out_h, int* out_w);
+int cough_resblock_forward(const cough_resblock* m, const float* d_x, int n, int height, int width, float* d_y,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ conv-block classifiers
  * Replaces CoughDetector.forward / predict (/root/reference/src/model.py:43-141, ConvBlock :11-40) and
  * CoughDetectorSmall.forward / predict (:144-207) in eval mode.  Both are a stack of blocks

@@ -1,4 +1,5 @@
-"""Generate ``tests/golden/resnet_channels_golden.npz``: reference outputs for NON-default ``channels`` tuples.
+"""Generate ``tests/golden/resnet_channels_golden.npz`` (reference outputs for NON-default ``channels`` tuples) and
+``tests/golden/resblock_golden.npz`` (the reference ``ResidualBlock`` called on its own, identity skip included).
 
 Run in the BUILD CONTAINER only (needs ``/root/reference``):
 
@@ -26,6 +27,9 @@ from oracle.make_golden import MARGIN_STD, OUT, load_reference_model_module     
 
 CASES = {"deep": (16, 24, 40, 72), "square": (48, 48)}
 N_CLIPS = 6
+# ResidualBlock used directly (model.py:268-293): (in_channels, out_channels, stride); "identity" is the nn.Identity skip
+BLOCKS = {"identity": (16, 16, 1), "proj_s1": (24, 40, 1), "proj_s2": (32, 64, 2), "same_s2": (48, 48, 2)}
+BLOCK_INPUT = (3, 13, 17)      # batch, height, width
 
 
 def main():
@@ -68,6 +72,32 @@ def main():
         print(name, channels, "logits", logits.numpy().round(3).tolist(), "preds", preds.tolist())
     path = os.path.join(OUT, "resnet_channels_golden.npz")
     np.savez_compressed(path, n_clips=N_CLIPS, **out)
+    print(path, os.path.getsize(path))
+
+    blocks = {}
+    for name, (cin, cout, stride) in BLOCKS.items():
+        torch.manual_seed(1000 + cin * 7 + cout * 3 + stride)
+        blk = ref.ResidualBlock(cin, cout, stride=stride).eval()
+        g = torch.Generator().manual_seed(cin + cout + stride)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                c = m.num_features
+                m.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(c, generator=g) * 1.5 + 0.25)
+                m.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+                m.bias.data.copy_(torch.randn(c, generator=g) * 0.2)
+        xb = torch.randn(BLOCK_INPUT[0], cin, BLOCK_INPUT[1], BLOCK_INPUT[2], generator=g)
+        with torch.no_grad():
+            yb = blk(xb)
+        blocks[f"{name}.cfg"] = np.array([cin, cout, stride], dtype=np.int32)
+        blocks[f"{name}.x"] = xb.numpy()
+        blocks[f"{name}.y"] = yb.numpy()
+        for k, v in blk.state_dict().items():
+            blocks[f"{name}.sd.{k}"] = v.detach().numpy()
+        print("block", name, (cin, cout, stride), "identity skip" if isinstance(blk.skip, torch.nn.Identity) else "projection",
+              tuple(yb.shape), float(yb.abs().max()))
+    path = os.path.join(OUT, "resblock_golden.npz")
+    np.savez_compressed(path, **blocks)
     print(path, os.path.getsize(path))
 
 

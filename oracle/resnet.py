@@ -37,6 +37,18 @@ def res_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int) -> torch.Ten
     return F.relu(out + identity)
 
 
+def res_block_module(x: torch.Tensor, sd: Dict[str, torch.Tensor], stride: int) -> torch.Tensor:
+    """One ResidualBlock on its own (model.py:268-293), state_dict keys of the block itself: the skip is the 1x1
+    stride-s conv + BN when the block has one (``skip.0.weight`` present) and the identity otherwise (:280-283)."""
+    if "skip.0.weight" in sd:
+        identity = _bn(F.conv2d(x, sd["skip.0.weight"], sd["skip.0.bias"], stride=stride), sd, "skip.1")
+    else:
+        identity = x
+    out = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], stride=stride, padding=1), sd, "bn1"))
+    out = _bn(F.conv2d(out, sd["conv2.weight"], sd["conv2.bias"], padding=1), sd, "bn2")
+    return F.relu(out + identity)
+
+
 def head(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
     """M4 -- model.py:242-247,257-258: global mean -> Linear(128, 2)."""
     return F.linear(x.mean(dim=(2, 3)), sd["fc.2.weight"], sd["fc.2.bias"])

@@ -61,6 +61,22 @@ def resnet_channels_golden():
 
 
 @pytest.fixture(scope="session")
+def resblock_golden():
+    """{case: ((in_ch, out_ch, stride), state_dict, x, y)}: the reference ResidualBlock called on its own
+    (oracle/make_golden_channels.py), "identity" being the nn.Identity skip."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(GOLDEN, "resblock_golden.npz"))
+    cases = {}
+    for name in sorted({k.split(".")[0] for k in g.files}):
+        pre = name + ".sd."
+        sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+        cases[name] = (tuple(int(v) for v in g[name + ".cfg"]), sd, torch.from_numpy(g[name + ".x"]),
+                       torch.from_numpy(g[name + ".y"]))
+    return cases
+
+
+@pytest.fixture(scope="session")
 def features_golden():
     import numpy as np
     g = np.load(os.path.join(GOLDEN, "features_golden.npz"))
