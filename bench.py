@@ -11,8 +11,9 @@ A step is one pass of the hot path over one batch of B = 4096 synthetic clips th
 (BASELINE.json configs[2]).  The clips are generated ON THE DEVICE from their global index (``cough_synth_clips``) and
 the steps rotate over ``--rotate`` distinct batches (default 3 x 262 MB > 2 x the 256 MiB Infinity Cache), so every
 step's waveform read comes from HBM.  With N ranks the clip stream is sharded round-robin (clip i -> rank i mod N,
-weak scaling: every rank runs B clips per step) and the only exchange is an RCCL all-gather of the (B, 2) logits per
-step.  ``--total-clips T`` runs configs[3] as worded: a T-clip stream (default use: 1 000 000), every clip distinct,
+weak scaling: every rank runs B clips per step) and the only exchange is an RCCL all-gather of the ranks' logits, one
+per bucket of ``--gather-every`` steps (default 8: 256 KB per rank), overlapped with the next bucket's compute and
+finished inside the timed region.  ``--total-clips T`` runs configs[3] as worded: a T-clip stream (default use: 1 000 000), every clip distinct,
 sharded round-robin and resident in HBM (64 KB per clip), one pass.  Rank 0 prints ONE JSON line.
 
 Before ``--warmup`` an untimed pre-warm (``--prewarm-s``, default 0.6 s of the same pipeline, reported as
