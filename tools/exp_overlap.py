@@ -31,10 +31,14 @@ def main():
     wav = torch.from_numpy(make_clips(0, args.batch, peak_normalize=False)).to(dev)
     ref = CoughPipeline(pre, model)(wav).clone()
 
-    def run(n_streams, n_chunks):
+    def run(n_streams, n_chunks, prio=False):
         parts = n_streams * n_chunks
         sz = args.batch // parts
-        streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+        # prio: stream 0 outranks stream 1 (outranks 2 ...): the dispatcher fills a kernel's tail with the next stream's
+        # workgroups instead of running the halves side by side
+        lo, hi = torch.cuda.Stream.priority_range()
+        pr = [max(hi, min(lo, hi + k)) for k in range(n_streams)] if prio else [0] * n_streams
+        streams = [torch.cuda.Stream(dev, priority=pr[k]) for k in range(n_streams)]
         pipes = [CoughPipeline(pre, model) for _ in range(parts)]
         outs = [None] * parts
 
@@ -58,10 +62,11 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         got = torch.cat(outs)
         same = bool((got == ref).all())
-        print(f"streams={n_streams} chunks/stream={n_chunks}  {ms:.4f} ms/step  {args.batch / ms / 1e3:.3f} M clips/s  "
+        print(f"streams={n_streams} chunks/stream={n_chunks} prio={pr}  {ms:.4f} ms/step  {args.batch / ms / 1e3:.3f} M clips/s  "
               f"bit-identical={same}", flush=True)
 
-    for cfg in [(1, 1), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (1, 2), (1, 1)]:
+    print("priority range (lowest, highest):", torch.cuda.Stream.priority_range())
+    for cfg in [(1, 1), (2, 1), (2, 1, True), (2, 2, True), (4, 1, True), (2, 1), (2, 1, True), (1, 1)]:
         run(*cfg)
 
 
