@@ -146,8 +146,9 @@ typedef struct cough_resnet cough_resnet;
 int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype);
 /* The same for any `channels` tuple of CoughDetectorResidual.__init__ (/root/reference/src/model.py:216-247):
  * channels[0 .. n_blocks] = (stem out, block 0 out, ..., block n_blocks-1 out); blocks[i] holds res_blocks.i;
- * fc_w is fc.2.weight [2][channels[n_blocks]].  Tuples other than (32, 64, 128) run on the exact-f32 kernels
- * whatever `dtype` asks for (channel counts padded to multiples of 32 in device memory). */
+ * fc_w is fc.2.weight [2][channels[n_blocks]].  A model created here ALWAYS runs on the exact-f32 kernels, whatever
+ * `dtype` asks for (channel counts padded to multiples of 32 in device memory); the fused split-bf16 / bf16 kernels
+ * are compiled for the shipped (32, 64, 128) and reached through cough_resnet_create. */
 int cough_resnet_create_ex(cough_resnet** out, int n_blocks, const int* channels, const cough_conv_bn* stem,
                            const cough_resblock_weights* blocks, const float* fc_w, const float* fc_b, float bn_eps,
                            int dtype);
