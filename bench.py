@@ -156,9 +156,12 @@ def build_launch_cmd(argv, n_ranks: int, port: int):
 
 
 def launch_ranks(args, argv) -> int:
-    """Parent of a multi-rank run: no GPU call is made here (device_count() does not initialise the runtime)."""
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    """Parent of a multi-rank run.  It stays subprocess-only and never touches the GPU runtime: devices are counted
+    from the KFD topology in sysfs (``hostcpu.visible_gpu_count``), not with ``torch.cuda.device_count()``, which may
+    initialise HIP.  When the topology cannot be read the check is skipped and the ranks report a shortage."""
+    from cough_detector_amd.hostcpu import visible_gpu_count
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus:
         print(f"bench.py --gpus {args.gpus}: only {have} device(s) visible on this node "
               f"(ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES?)", file=sys.stderr)
         return 2
@@ -211,6 +214,10 @@ def main():
     args.gpus = world
     from cough_detector_amd.hostcpu import bound_torch_threads
     bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
+    if torch.cuda.device_count() <= local_rank:       # a rank may touch the runtime; the launching parent may not
+        print(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible on this node "
+              f"(rank {rank} needs device {local_rank})", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -228,21 +235,15 @@ def main():
 
     import cough_detector_amd as cda
     from cough_detector_amd import synth
-    from cough_detector_amd.distributed import BucketedLogitsGather, local_count
+    from cough_detector_amd.distributed import BucketedLogitsGather, stream_shard
 
     B, W = args.batch, args.warmup
     # rank r owns global clips r, r+N, r+2N, ... (round-robin); clip g is generated on the device from seed g
     if args.total_clips > 0:
-        n_local = local_count(args.total_clips, rank, world)
-        K = (local_count(args.total_clips, 0, world) + B - 1) // B          # steps of the rank with the most clips
-        pool = torch.empty((max(n_local, 1), 16000), dtype=torch.float32, device=dev)
-        for j in range(0, n_local, B):
-            c = min(B, n_local - j)
-            synth.device_clips(rank + j * world, c, seed_stride=world, out=pool[j:j + c])
-        batches = [pool[j * B:min((j + 1) * B, n_local)] for j in range(K)]
-        step_total = [min(args.total_clips, (j + 1) * B * world) - j * B * world for j in range(K)]
+        batches, step_total = stream_shard(args.total_clips, B, rank, world, dev)
+        K = len(batches)                                                     # steps of the rank with the most clips
     else:
-        K, n_local = args.steps, None
+        K = args.steps
         R = max(1, args.rotate)
         pool = torch.empty((R * B, 16000), dtype=torch.float32, device=dev)
         for j in range(R):
@@ -323,15 +324,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    full = [i for i in range(K) if batches[i].shape[0] == B]       # kernel times are quoted on full batches
+    # kernel times are quoted on full batches; a --total-clips stream shorter than one batch has only a ragged step
+    full = [i for i in range(K) if batches[i].shape[0] == B] or [i for i in range(K) if batches[i].shape[0] > 0]
+    Bk = batches[full[0]].shape[0] if full else 0                  # clips per launch the kernel figures refer to
     k1_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in full) / max(len(full), 1)
     net_ms = 0.0 if args.featurize_only else sum(ev[i][1].elapsed_time(ev[i][2]) for i in full) / max(len(full), 1)
 
     if rank == 0:
         total_clips = sum(step_total)
         k1_bytes = BYTES_PER_CLIP_FUSED[args.dtype] if fused else BYTES_PER_CLIP
-        achieved = B * k1_bytes / (k1_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(B, ("k1_fused_" + args.dtype) if fused else "k1")
+        achieved = Bk * k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(Bk, ("k1_fused_" + args.dtype) if fused else "k1")
         if args.featurize_only:
             workload = "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32"
         elif args.total_clips > 0:
@@ -361,10 +364,10 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": round(k1_ms, 4),
-                         "algorithmic_bytes_per_launch": B * k1_bytes},
+                         "algorithmic_bytes_per_launch": Bk * k1_bytes, "clips_per_launch": Bk},
         }
-        if not args.featurize_only:
-            tf = B * (FLOP_PER_CLIP_NO_STEM if fused else FLOP_PER_CLIP) / (net_ms * 1e-3) / 1e12
+        if not args.featurize_only and net_ms > 0:
+            tf = Bk * (FLOP_PER_CLIP_NO_STEM if fused else FLOP_PER_CLIP) / (net_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             line["roofline_classifier"] = {"kernel": "residual blocks + head (K3-K5)" + ("" if fused else " + stem (K2)"),
                                            "bound": "mfma",
@@ -372,8 +375,9 @@ def main():
                                            "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4),
                                            "mfma_per_product": MFMA_PER_PRODUCT[args.dtype],
                                            "mfma_issue_frac": round(MFMA_PER_PRODUCT[args.dtype] * tf / peak, 4)}
-        if world == 1 and not dist:
-            line["roofline_stft"] = stft_stage(pre, [b_ for b_ in batches[:8] if b_.shape[0] == B] or [pool[:B]])
+        stft_in = [b_ for b_ in batches[:8] if b_.shape[0] == B]
+        if world == 1 and not dist and stft_in:
+            line["roofline_stft"] = stft_stage(pre, stft_in)
         if world == 1 and not dist and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if dist:

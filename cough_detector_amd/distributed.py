@@ -141,3 +141,68 @@ class BucketedLogitsGather:
         self.flush()
         self._finish()
         return self.out[:self.last_n]
+
+
+def stream_shard(total_clips: int, batch: int, rank: int, world: int, device):
+    """configs[3]'s input: this rank's round-robin shard of a ``total_clips``-clip synthetic stream, generated ON THE
+    DEVICE from the clips' global indices (clip ``g`` = ``synth.make_clip_counter(g)``, the recipe of
+    ``/root/reference/setup_coughvid.py:381-441``) and kept resident in HBM (64 KB per clip).
+
+    Returns ``(batches, step_total)``: ``batches[j]`` holds local clips ``j*batch .. (j+1)*batch-1`` of this rank
+    (global clips ``rank + (j*batch + k)*world``), possibly short or empty on the last steps of a ragged stream;
+    ``step_total[j]`` is the number of clips ALL ranks score in step ``j``.  Every rank runs the same number of
+    steps (those of the fullest rank), so the bucketed exchange below stays collective."""
+    from . import synth
+    n_local = local_count(total_clips, rank, world)
+    steps = (local_count(total_clips, 0, world) + batch - 1) // batch
+    pool = torch.empty((max(n_local, 1), synth.N), dtype=torch.float32, device=device)
+    for j in range(0, n_local, batch):
+        c = min(batch, n_local - j)
+        synth.device_clips(rank + j * world, c, seed_stride=world, out=pool[j:j + c])
+    batches = [pool[j * batch:min((j + 1) * batch, n_local)] for j in range(steps)]
+    step_total = [min(total_clips, (j + 1) * batch * world) - j * batch * world for j in range(steps)]
+    return batches, step_total
+
+
+def score_stream(pipeline, total_clips: int, batch: int = 4096, every: int = 8, group=None,
+                 rank: Optional[int] = None, world: Optional[int] = None, device=None, shard=None) -> torch.Tensor:
+    """Score a ``total_clips``-clip synthetic stream sharded round-robin over the ranks of ``group`` and return the
+    logits of EVERY clip, in global clip order, on every rank: ``(total_clips, 2)``.
+
+    This is configs[3] end to end: ``stream_shard`` -> ``CoughPipeline`` per step -> ``BucketedLogitsGather`` (one
+    RCCL all-gather per ``every`` steps, overlapped with the next bucket) -> un-interleave.  Without an initialised
+    process group (``rank`` / ``world`` given explicitly, or a single process) it returns only this rank's rows in
+    local order -- the gather needs its peers.  ``shard`` replaces ``stream_shard`` (same signature; the gloo tests
+    feed index-carrying CPU batches through a stand-in pipeline)."""
+    have_group = dist.is_available() and dist.is_initialized()
+    if rank is None:
+        rank = dist.get_rank(group) if have_group else 0
+    if world is None:
+        world = dist.get_world_size(group) if have_group else 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    batches, step_total = (shard or stream_shard)(total_clips, batch, rank, world, device)
+    if not have_group:
+        parts = [pipeline(b, normalize=True) for b in batches if b.shape[0]]
+        return torch.cat(parts) if parts else torch.empty((0, 2), device=device)
+    pub = BucketedLogitsGather(batch, every, device, group=group)
+    full = torch.empty((total_clips, 2), dtype=torch.float32, device=device)
+    done, copied = 0, 0
+
+    def collect():
+        nonlocal done, copied
+        if pub.finished > copied:                    # a bucket landed in ``out``: global clips done .. done+last_n-1
+            full[done:done + pub.last_n].copy_(pub.out[:pub.last_n])
+            done += pub.last_n
+            copied = pub.finished
+
+    for j, wav in enumerate(batches):
+        pub.push(pipeline(wav, normalize=True), step_total[j])
+        collect()
+    pub.flush()
+    collect()
+    pub.drain()
+    collect()
+    if done != total_clips:
+        raise RuntimeError(f"stream exchange incomplete: {done} of {total_clips} clips gathered")
+    return full

@@ -153,13 +153,15 @@ def main(argv=None):
     parser.add_argument("--input", type=str, default=None,
                         help=".npy file with a 16 kHz mono float32 stream (default: a synthetic stream)")
     parser.add_argument("--seconds", type=float, default=10.0, help="Length of the synthetic stream")
+    parser.add_argument("--compute-dtype", type=str, default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                        help="classifier arithmetic (fp32 = exact-f32 MFMA; bf16x3 = split-bf16, the throughput mode)")
     args = parser.parse_args(argv)
     if args.list_devices:
         print("No audio capture back-end in this build; pass --input stream.npy or use the synthetic stream.")
         return
     engine = CoughDetectorInference(model_path=args.model, device=args.device, confidence_threshold=args.threshold,
                                     smoothing_window=args.smoothing, debounce_seconds=args.debounce,
-                                    verbose=not args.quiet)
+                                    verbose=not args.quiet, compute_dtype=args.compute_dtype)
     if args.input:
         stream = np.load(args.input).astype(np.float32).reshape(-1)
     else:
@@ -167,18 +169,19 @@ def main(argv=None):
         stream = make_stream(0, args.seconds)
     sr = engine.config.get("sample_rate", 16000)
     chunk = int(sr * 0.1)
-    t0, detections = time.time(), 0
+    t0, detections = time.time(), []
     sim = {"t": 0.0}
     engine._clock = lambda: sim["t"]        # stream time, not wall time: 0.1 s per chunk
     for i in range(0, len(stream) - chunk + 1, chunk):
         sim["t"] = (i + chunk) / sr
         hit = engine.process_audio_chunk(stream[i:i + chunk])
         if hit is not None:
-            detections += 1
+            detections.append((sim["t"], hit[1]))
             if not args.quiet:
                 print(f"[{sim['t']:7.2f}s] COUGH DETECTED (confidence: {hit[1]:.1%})")
     if not args.quiet:
-        print(f"{len(engine.window_probs)} windows, {detections} detections, {time.time() - t0:.2f} s wall")
+        print(f"{len(engine.window_probs)} windows, {len(detections)} detections, {time.time() - t0:.2f} s wall")
+    return {"detections": detections, "window_probs": list(engine.window_probs)}
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ exact sub-module layout, so ``state_dict()`` / ``load_state_dict()`` use the ref
 """
 from __future__ import annotations
 
+import warnings
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -132,7 +133,8 @@ class CoughDetectorResidual(nn.Module):
         self.channels = channels          # (32, 64, 128): the fused kernels; any other tuple: the exact-f32 kernels
         if compute_dtype not in ("fp32", "bf16", "bf16x3", "_direct"):
             raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
-        self.compute_dtype = compute_dtype
+        self.compute_dtype = compute_dtype            # what was asked for; ``effective_dtype`` is what runs
+        self._warned_fallback = set()
         self.conv1 = nn.Sequential(nn.Conv2d(in_channels, channels[0], 7, stride=2, padding=3),
                                    nn.BatchNorm2d(channels[0]), nn.ReLU(), nn.MaxPool2d(2))
         self.res_blocks = nn.ModuleList()
@@ -223,6 +225,29 @@ class CoughDetectorResidual(nn.Module):
         return h
 
     # ------------------------------------------------------------------ forward
+    def effective_dtype(self, height: int = 90, width: int = 101) -> str:
+        """The arithmetic that actually runs for a ``(height, width)`` feature image.  The fused reduced-precision
+        kernels are compiled for the shipped ``channels=(32, 64, 128)`` (``cough_resnet_create``); any other tuple
+        goes through ``cough_resnet_create_ex`` onto the exact-f32 MFMA kernels, and the split-bf16 residual blocks
+        are compiled for the shipped 90x101 image (block inputs 22x25 and 11x13) -- another image size runs them
+        in exact f32 as well.  Results are at least as accurate as asked for; throughput is the f32 path's."""
+        if self.compute_dtype in ("fp32", "_direct"):
+            return self.compute_dtype
+        if self.channels != (32, 64, 128):
+            return "fp32"
+        if self.compute_dtype == "bf16x3" and (height, width) != (90, 101):
+            return "fp32"
+        return self.compute_dtype
+
+    def _warn_fallback(self, height: int, width: int) -> None:
+        eff = self.effective_dtype(height, width)
+        if eff != self.compute_dtype and (height, width) not in self._warned_fallback:
+            self._warned_fallback.add((height, width))
+            why = (f"channels={self.channels}" if self.channels != (32, 64, 128) else f"a {height}x{width} feature image")
+            warnings.warn(f"CoughDetectorResidual: compute_dtype={self.compute_dtype!r} is not compiled for {why}; "
+                          f"running the exact-f32 MFMA kernels instead (same or better accuracy, several times slower). "
+                          f"See effective_dtype().", UserWarning, stacklevel=4)
+
     def _run(self, x: torch.Tensor, want_probs: bool):
         if self.training:
             raise RuntimeError("CoughDetectorResidual on the MI355X path is inference-only: call .eval()")
@@ -237,6 +262,7 @@ class CoughDetectorResidual(nn.Module):
         if b == 0:
             z = torch.empty((0, 2), dtype=torch.float32, device=src_dev)
             return (z, z.clone(), torch.empty((0,), dtype=torch.int32, device=src_dev)) if want_probs else z
+        self._warn_fallback(hgt, wid)
         lib, h = _lib.load(), self._native()
         need = lib.cough_resnet_workspace_bytes(h, b, hgt, wid)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:

@@ -89,3 +89,42 @@ def test_shard_helpers():
             assert sum(counts) == n and max(counts) - min(counts) <= 1
             allidx = torch.cat([cdist.local_indices(n, r, world) for r in range(world)]).sort().values
             assert torch.equal(allidx, torch.arange(n))
+
+
+def _index_shard(total, batch, rank, world, device):
+    """Stand-in for ``stream_shard`` on CPU: a batch row carries its clip's GLOBAL index instead of a waveform."""
+    idx = cdist.local_indices(total, rank, world)[:cdist.local_count(total, rank, world)].float()
+    steps = (cdist.local_count(total, 0, world) + batch - 1) // batch
+    batches = [idx[j * batch:(j + 1) * batch, None] for j in range(steps)]
+    step_total = [min(total, (j + 1) * batch * world) - j * batch * world for j in range(steps)]
+    return batches, step_total
+
+
+def _score_worker(rank, world, port, n_total, batch, every):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake_pipeline = lambda b, normalize=True: torch.cat([b, -b], dim=1)      # "logits" of clip i = (i, -i)
+        full = cdist.score_stream(fake_pipeline, n_total, batch=batch, every=every, device="cpu", shard=_index_shard)
+        want = torch.stack([torch.arange(n_total).float(), -torch.arange(n_total).float()], dim=1)
+        assert torch.equal(full, want), (rank, full[:6], full[-6:])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,batch,every", [(2, 101, 8, 3), (3, 50, 4, 2), (2, 7, 8, 8), (2, 33, 16, 1)])
+def test_score_stream_returns_every_clip_in_global_order_gloo(world, n_total, batch, every):
+    """configs[3]'s driver loop (shard -> score -> bucketed exchange -> collect) with W > 1, ragged tails and a
+    rank whose last step is empty."""
+    mp.spawn(_score_worker, args=(world, _free_port(), n_total, batch, every), nprocs=world, join=True)
+
+
+def test_stream_shard_bookkeeping_matches_score_stream_contract():
+    for world in (1, 2, 3, 8):
+        for total, batch in ((0, 4), (1, 4), (9, 4), (64, 8), (37, 8)):
+            shards = [_index_shard(total, batch, r, world, "cpu") for r in range(world)]
+            assert len({len(b) for b, _ in shards}) == 1                    # same number of steps on every rank
+            for j, tot in enumerate(shards[0][1]):
+                assert sum(s[0][j].shape[0] for s in shards) == tot
+            assert sum(shards[0][1]) == total

@@ -38,12 +38,21 @@ def test_residual_net_random_image_sizes(dtype, tol):
     m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
     m.load_state_dict(sd)
     m.cuda()
+    import warnings
     for _ in range(6):
         b, f, t = int(rng.integers(1, 19)), int(rng.integers(24, 140)), int(rng.integers(24, 140))
         x = torch.rand((b, 1, f, t), generator=torch.Generator().manual_seed(b * 1000 + f))
-        got = m(x.cuda()).cpu()
+        with warnings.catch_warnings(record=True) as rec:           # the fallback is announced, never silent
+            warnings.simplefilter("always")
+            got = m(x.cuda()).cpu()
+        assert m.effective_dtype(f, t) == "fp32"
+        assert (dtype == "bf16x3") == any("exact-f32 MFMA kernels instead" in str(w.message) for w in rec)
         want = ores.forward(x, sd)
         assert float((got - want).abs().max()) < tol, (b, f, t)
+    with warnings.catch_warnings():                                   # the shipped image never warns
+        warnings.simplefilter("error")
+        m(torch.rand(2, 1, 90, 101).cuda())
+    assert m.effective_dtype() == dtype
 
 
 @pytest.mark.parametrize("kind", ["standard", "small"])

@@ -170,3 +170,35 @@ def test_spec_augment_draw_order_matches_oracle():
     x = torch.ones(1, 4, 4)
     random.seed(0)
     assert SpecAugment(p=0.0)(x) is x                       # the coin (python `random`) says no: input returned as is
+
+
+def test_visible_gpu_count_reads_sysfs_without_the_runtime(tmp_path):
+    """bench.py's multi-rank parent counts devices from the KFD topology (no HIP call): CPU nodes are skipped,
+    *_VISIBLE_DEVICES and the render nodes this process may open cut the count down."""
+    from cough_detector_amd.hostcpu import visible_gpu_count
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):                     # 2 CPU sockets + 3 GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    assert visible_gpu_count(str(nodes), environ={}, dri_root=str(tmp_path / "missing")) == 3
+    assert visible_gpu_count(str(nodes), environ={"HIP_VISIBLE_DEVICES": "0,2"}, dri_root=str(tmp_path / "missing")) == 2
+    assert visible_gpu_count(str(nodes), environ={"ROCR_VISIBLE_DEVICES": ""}, dri_root=str(tmp_path / "missing")) == 0
+    (dri / "renderD128").write_text("")
+    (dri / "card0").write_text("")
+    assert visible_gpu_count(str(nodes), environ={}, dri_root=str(dri)) == 1            # one render node handed in
+    assert visible_gpu_count(str(tmp_path / "absent"), environ={}) is None
+
+
+def test_effective_dtype_reports_the_kernels_that_run():
+    """A reduced-precision request the compiled kernels do not cover is reported (and warned about at the first
+    forward, tests/test_gpu_fuzz.py), not silently replaced."""
+    import cough_detector_amd as cda
+    m = cda.create_model("residual", n_mels=90, compute_dtype="bf16x3")
+    assert m.compute_dtype == "bf16x3" and m.effective_dtype() == "bf16x3" and m.effective_dtype(64, 101) == "fp32"
+    wide = cda.CoughDetectorResidual(channels=(16, 24, 40), compute_dtype="bf16x3")
+    assert wide.effective_dtype() == "fp32" and wide.compute_dtype == "bf16x3"
+    assert cda.create_model("residual", compute_dtype="fp32").effective_dtype(33, 77) == "fp32"
+    assert cda.create_model("residual", compute_dtype="bf16").effective_dtype() == "bf16"

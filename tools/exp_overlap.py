@@ -33,7 +33,8 @@ def main():
 
     def run(n_streams, n_chunks, prio=False):
         parts = n_streams * n_chunks
-        sz = args.batch // parts
+        # uneven splits (e.g. 4096 over 3 parts) hand the remainder to the first parts: every clip is scored
+        cuts = [args.batch * p // parts for p in range(parts + 1)]
         # prio: stream 0 outranks stream 1 (outranks 2 ...): the dispatcher fills a kernel's tail with the next stream's
         # workgroups instead of running the halves side by side
         lo, hi = torch.cuda.Stream.priority_range()
@@ -49,7 +50,7 @@ def main():
             for p in range(parts):
                 s = streams[p % n_streams]
                 with torch.cuda.stream(s):
-                    outs[p] = pipes[p](wav[p * sz:(p + 1) * sz])
+                    outs[p] = pipes[p](wav[cuts[p]:cuts[p + 1]])
             for s in streams:
                 main_s.wait_stream(s)
         for _ in range(5):

@@ -18,12 +18,12 @@ model.load_state_dict(synth.random_state_dict(seed=3)); model.cuda()
 x = torch.rand(B, 1, 90, 101, device="cuda")
 model(x)
 lib.cough_debug_set_rb_stamp_buffer.argtypes = [C.c_void_p]
-stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(B * 8, dtype=torch.int64, device="cuda")
 assert lib.cough_debug_set_rb_stamp_buffer(stamps.data_ptr()) == 0
 model(x); torch.cuda.synchronize()
 assert lib.cough_debug_set_rb_stamp_buffer(None) == 0
 # both block kernels wrote the same buffer; block1 ran last with ceil(B/3) workgroups, block0 with B/2 before it
-st = stamps.view(4096, 8).cpu().double()
+st = stamps.view(B, 8).cpu().double()
 n1 = (B + 2) // 3
 for name, rows in (("block1 (G=3, 8 waves)", st[:n1]), ("block0 (G=1, 4 waves) [rows not overwritten by block1]", st[n1:B])):
     d = rows[:, 1:7] - rows[:, 0:6]; total = rows[:, 6] - rows[:, 0]

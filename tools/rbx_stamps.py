@@ -24,12 +24,12 @@ x = torch.rand(B, 1, 90, 101, device="cuda")
 for _ in range(20):
     model(x)
 lib.cough_debug_set_rb_stamp_buffer.argtypes = [C.c_void_p]
-stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(B * 8, dtype=torch.int64, device="cuda")   # block 0 writes row blockIdx.x < B
 assert lib.cough_debug_set_rb_stamp_buffer(stamps.data_ptr()) == 0
 model(x); torch.cuda.synchronize()
 assert lib.cough_debug_set_rb_stamp_buffer(None) == 0
 # both block kernels wrote the same buffer: block 1 ran last with B/2 workgroups, block 0 with B before it
-st = stamps.view(4096, 8).cpu().double()
+st = stamps.view(B, 8).cpu().double()
 n1 = (B + 1) // 2
 for name, rows in (("block1 (G=2)", st[:n1]), ("block0 (G=1) [rows not overwritten by block1]", st[n1:B])):
     d = rows[:, 1:8] - rows[:, 0:7]; total = rows[:, 7] - rows[:, 0]
