@@ -16,6 +16,8 @@
 // (ids are dealt round-robin over the 8 XCDs), dispatched together, so the fragments of one 404-byte row meet in
 // that XCD's L2 and leave as whole lines: WRITE_SIZE = 1.004x the algorithmic bytes (1.34x with one workgroup
 // per clip flushing chunk after chunk; 1.29x with a persistent grid, whose sibling workgroups drift apart).
+#include <cstdlib>
+
 #include "common.h"
 #include "fft256.h"
 #include "internal.h"
@@ -40,6 +42,19 @@ constexpr size_t LDS_TW = size_t(16) * XROW * 8;               // 2176
 constexpr size_t LDS_TOTAL = LDS_XCH + LDS_TW + LDS_PW;
 static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
 static_assert(LDS_XCH % 16 == 0 && LDS_TW % 16 == 0, "float2 table and staging rows start 16-byte aligned");
+
+#ifdef COUGH_K1_STAMPS
+// Diagnostic build only (tools/stft_stamps.py): s_memtime of wave 0 and wave 3 at phase boundaries, into a buffer of
+// its own that no other code reads.  Never compiled into libcough_amd.so.
+__device__ unsigned long long* g_stft_stamp_buf = nullptr;
+#define STFT_STAMP(slot)                                                                              \
+    do {                                                                                              \
+        if (g_stft_stamp_buf && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
+            g_stft_stamp_buf[(size_t(blockIdx.x) * 2 + (threadIdx.x >> 7)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STFT_STAMP(slot) do {} while (0)
+#endif
 
 // FULLWIN: all 512 window taps are live (Hann(512)); otherwise taps [0,56) and [456,512) are zero (Hann(400)
 // centred in the frame) and the first / last 32-sample slabs are never loaded.
@@ -83,6 +98,7 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
         }
     };
     if (clip >= n_clips) return;   // workgroup-uniform: the last slab of 8 clips may be partial
+    STFT_STAMP(0);
     float2 raw[16];
     load_group(wav + clip * wav_stride, CHUNK_G0[chunk] + wave, raw);
     // window taps and the W256 table arrive while the first samples are on their way from HBM
@@ -94,6 +110,7 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
     }
     twl[(tid >> 4) * XROW + (tid & 15)] = tw256[tid];
     __syncthreads();
+    STFT_STAMP(1);
 
     {
         const float* x = wav + clip * wav_stride;
@@ -109,6 +126,10 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
             for (int n1 = N0; n1 < N1; ++n1) a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
             // the raw registers are free: the wave's second group starts moving now and lands during this FFT
             if (g + WAVES < ge) load_group(x, g + WAVES, raw);
+#ifdef COUGH_K1_STAMPS
+            asm volatile("" :: "v"(a[1].x));   // the window multiply has consumed the samples: they have arrived
+            if (g == gs + wave) STFT_STAMP(2);
+#endif
             dft16(a);
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
@@ -157,8 +178,13 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
                 if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
             }
             wave_lds_fence();
+#ifdef COUGH_K1_STAMPS
+            if (g == gs + wave) STFT_STAMP(3);
+#endif
         }
+        STFT_STAMP(4);
         __syncthreads();
+        STFT_STAMP(5);
         {
             const int t0 = gs * FPW;
             const int nv = (ge * FPW < NFRAMES ? ge * FPW : NFRAMES) - t0;
@@ -174,9 +200,241 @@ __global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restric
                 if (r0 == 0) dst[256 * NFRAMES] = src[256 * PITCH];
             }
         }
+#ifdef COUGH_K1_STAMPS
+        STFT_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STFT_STAMP(7);
+#endif
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// stft3_kernel: one PERSISTENT 13-wave workgroup per CU, one clip at a time, whole spectrogram staged in LDS.
+//
+// Why: the (bin, time) output is time-minor with 404-byte rows, so a workgroup that owns a range of frames writes
+// 60-110-byte row fragments at 4-byte alignment and relies on sibling workgroups' fragments meeting in L2 (stft_kernel
+// above).  Here a workgroup owns the clip's WHOLE 257 x 101 spectrogram -- one contiguous 103 828-byte range of the
+// output -- builds it in LDS as the linear image it is in memory, and writes it with 16-byte-per-lane stores at
+// 16-byte-aligned addresses: every 128-byte line leaves the CU whole, once, in one burst.
+//   * 26 four-frame groups = 13 waves x 2 rounds exactly; the clip's image (103.8 KB) + 13 transpose scratches of
+//     4 160 B + twiddle and window tables = 162 KB of the CU's 160 KiB (163 840 B).
+//   * A wave's 992 samples per group come straight from HBM into its transpose scratch by `global_load_lds_dwordx4`
+//     (no data VGPRs; reflected edges: dword DMAs with per-lane reflected source addresses), and the NEXT group's
+//     samples (the next clip's, in round 1) are requested as soon as the second transpose has been read back, so
+//     their latency runs under the second radix-16, the real-input split, the barriers and the flush.
+//   * The transpose scratch interleaves the wave's four frames: element (row k, frame f, column n) at 65 k + 16 f + n.
+//     Writes (lane = (f, j), row k1) are 64 consecutive floats, reads (row j, column n2) hit 32 distinct banks per
+//     half-wave, every address is a per-lane base + an immediate, and it takes 1040 floats instead of 4 x 272.
+//   * Raw `s_barrier`s behind `lgkmcnt(0)` (a `__syncthreads()` would drain the DMA); the samples are awaited with a
+//     counted `vmcnt` that leaves the flush stores issued after the DMA in flight.
+constexpr int W3 = 13, THREADS3 = W3 * 64;                              // 832 threads
+constexpr int GSPAN = (FPW - 1) * HOP + NFFT;                           // 992 samples feed one four-frame group
+constexpr int X3ROW = FPW * 16 + 1, X3WAVE = 16 * X3ROW;                // transpose scratch: [16 rows][4 frames x 16 + 1 pad]
+constexpr int IMG = NFREQ * NFRAMES;                                    // 25 957 floats
+constexpr int IMG_PIECES = (IMG + 3 + 3) / 4;                           // 16-byte pieces incl. up to 3 floats of lead-in
+constexpr size_t LDS3_IMG = size_t(IMG_PIECES) * 16;                    // 103 840
+constexpr size_t LDS3_XCH = size_t(W3) * X3WAVE * 4;                    // 54 080
+constexpr size_t LDS3_WIN = size_t(NFFT) * 4;                           // 2 048
+constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN;  // 162 144
+static_assert(LDS3_TOTAL <= 160 * 1024, "one workgroup owns the CU's LDS");
+static_assert(W3 * 2 == NGROUP, "13 waves x 2 rounds = 26 groups");
+static_assert(GSPAN <= X3WAVE && GSPAN % 4 == 0, "a group's samples land in the wave's transpose scratch");
+static_assert(LDS3_IMG % 16 == 0 && LDS3_XCH % 16 == 0 && LDS_TW % 16 == 0, "16-byte aligned regions");
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA by inline asm: the destination is M0 (wave-uniform LDS byte address) + lane * size.  hipcc does not count an
+// asm statement's memory operation, so it adds no `vmcnt(0)` of its own in front of the LDS reads -- the kernel waits
+// with a COUNTED `vmcnt` that leaves the flush stores issued after the DMA in flight (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);   // wave-uniform by construction; pins it to an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() {   // LDS hand-off between waves; leaves vector-memory ops in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef COUGH_K1_STAMPS
+#define STFT3_STAMP(slot) do { if (iter_no == 5) STFT_STAMP(slot); } while (0)
+#else
+#define STFT3_STAMP(slot) do {} while (0)
+#endif
+
+template <bool FULLWIN, bool MAG>
+__global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict__ wav, long long wav_stride,
+                                                         float* __restrict__ out, const float* __restrict__ win,
+                                                         const float2* __restrict__ tw256,
+                                                         const float2* __restrict__ tw512, int n_clips) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* img0 = reinterpret_cast<float*>(smem);                                       // the clip's image (+ lead-in)
+    float* xs = reinterpret_cast<float*>(smem + LDS3_IMG);                              // [W3][X3WAVE]
+    float2* twl = reinterpret_cast<float2*>(smem + LDS3_IMG + LDS3_XCH);                // [16][XROW]
+    float* winl = reinterpret_cast<float*>(smem + LDS3_IMG + LDS3_XCH + LDS_TW);        // [512]
+    constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, fsub = lane >> 4;
+    float* myw = xs + wave * X3WAVE;              // this wave's scratch: DMA landing zone, then the two transposes
+    float* xw = myw + 16 * fsub + j;              // transpose write base: row k1 at xw[k1 * X3ROW]
+    const float* xr = myw + X3ROW * j + 16 * fsub;   // transpose read base: column n2 at xr[n2]
+    const float2* tw_row = twl + j * XROW;
+    const unsigned myw_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)myw);
+
+    // request the 992 samples of group g of the clip at xc: scratch[i] = x[reflect(640 g - 256 + i)]
+    auto dma_group = [&](const float* xc, int g) {
+        const int s0 = FPW * HOP * g - PADL;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // the per-lane source offsets are loop-invariant across clips: keep hipcc from
+                                       // hoisting ~40 of them out of the persistent loop into VGPRs (it spilled 100+)
+        if (s0 >= 0 && s0 + GSPAN <= NS) {   // wave-uniform: groups 1..23
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int i = it * 64 + ln;   // 16-byte piece
+                if (i < GSPAN / 4) glds16(xc + s0 + 4 * i, myw_lds + it * 1024);
+            }
+        } else {   // reflect padding of torch.stft(center=True): per-lane source addresses, one dword each
+#pragma unroll
+            for (int it = 0; it < (GSPAN + 63) / 64; ++it) {
+                const int i = it * 64 + ln;
+                int sidx = s0 + i;
+                sidx = sidx < 0 ? -sidx : (sidx >= NS ? 2 * (NS - 1) - sidx : sidx);
+                if (i < GSPAN) glds4(xc + sidx, myw_lds + it * 256);
+            }
+        }
+    };
+
+    long long clip = blockIdx.x;
+    if (clip >= n_clips) return;
+    dma_group(wav + clip * wav_stride, wave);
+    const float2 tw_j = tw512[j];
+    if (tid < 256) twl[(tid >> 4) * XROW + (tid & 15)] = tw256[tid];
+    if (tid < 256) reinterpret_cast<float2*>(winl)[tid] = reinterpret_cast<const float2*>(win)[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first group's samples too (hipcc does not see the asm DMA)
+    __syncthreads();
+#ifdef COUGH_K1_STAMPS
+    int iter_no = 0;
+#endif
+
+    while (true) {
+        STFT3_STAMP(0);
+        const long long clip_n = clip + gridDim.x;
+        // the image sits `lead` floats into its region so that LDS and global addresses agree modulo 16 bytes
+        float* oc = out + clip * (long long)IMG;
+        const int lead = int((reinterpret_cast<size_t>(oc) >> 2) & 3);
+        float* img = img0 + lead;
+#pragma unroll 1
+        for (int rd = 0; rd < 2; ++rd) {
+            const int g = wave + W3 * rd;
+            // this group's samples are in the scratch.  Round 0: everything but the flush stores issued after the DMA
+            // (at least 7 per wave) has completed; round 1: nothing was issued after its DMA
+            if (rd == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (rd == 0) STFT3_STAMP(1);
+            float2 a[16], z[16];
+            if constexpr (!FULLWIN) {
+                a[0] = make_float2(0.f, 0.f);
+                a[15] = make_float2(0.f, 0.f);
+            }
+            const float* sp = myw + HOP * fsub + 2 * j;
+            const float* wp = winl + 2 * j;
+#pragma unroll
+            for (int n1 = N0; n1 < N1; ++n1) {
+                const float2 r = *reinterpret_cast<const float2*>(sp + 32 * n1);
+                const float2 w = *reinterpret_cast<const float2*>(wp + 32 * n1);
+                a[n1] = make_float2(r.x * w.x, r.y * w.y);
+            }
+            wave_lds_fence();
+            dft16(a);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) xw[k1 * X3ROW] = a[k1].x;
+            wave_lds_fence();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].x = xr[n2];
+            wave_lds_fence();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) xw[k1 * X3ROW] = a[k1].y;
+            wave_lds_fence();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].y = xr[n2];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is dead: every read of it has returned
+            if (rd == 0) STFT3_STAMP(2);
+            if (rd == 0) dma_group(wav + clip * wav_stride, wave + W3);
+            else if (clip_n < n_clips) dma_group(wav + clip_n * wav_stride, wave);
+            if (rd == 0) STFT3_STAMP(3);
+            dft16(z);   // z[k2] = Z[j + 16*k2]
+            float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror, then rotate right by one
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
+                rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
+            }
+            float* col = img + FPW * g + fsub;
+            auto put = [&](int bin, float pwr4) {   // pwr4 = |2X|^2
+                col[bin * NFRAMES] = MAG ? 0.5f * sqrtf(pwr4) : 0.25f * pwr4;
+            };
+            if (FPW * g + fsub < NFRAMES) {   // idle sub-frames of the last group store nothing
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 zk = z[k2];
+                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+                    // 2E = Zk + conj Zp, 2O = -i (Zk - conj Zp); 2X[k] = 2E + W^k 2O, 2X[256-k] = conj(2E - W^k 2O)
+                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+                    const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+                    const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+                    const int k = j + 16 * k2;
+                    put(k, ar * ar + ai * ai);
+                    put(NFFT / 2 - k, br * br + bi * bi);
+                }
+                if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
+            }
+            if (rd == 0) STFT3_STAMP(4);
+        }
+        STFT3_STAMP(5);
+        lds_barrier();
+        STFT3_STAMP(6);
+#ifndef COUGH_STFT_NO_STORE
+        {
+            // flush: the image is the clip's output range verbatim; piece p = LDS floats [4p, 4p + 4) = image elements
+            // [4p - lead, 4p - lead + 4) -> one 16-byte store at a 16-byte-aligned address.  The first and last piece
+            // may hold elements of the neighbouring clips' ranges: those two go out float by float.
+            const f32x4* src = reinterpret_cast<const f32x4*>(img0);
+            f32x4* dst = reinterpret_cast<f32x4*>(oc - lead);
+            const int last = (IMG + lead + 3) / 4 - 1;
+#pragma unroll
+            for (int it = 0; it < (IMG_PIECES + THREADS3 - 1) / THREADS3; ++it) {
+                const int p = tid + THREADS3 * it;
+                if (p > 0 && p < last) dst[p] = src[p];
+            }
+            if (tid < 8) {   // element e of the first (tid < 4) or last piece
+                const int e = (tid < 4 ? 0 : 4 * last) + (tid & 3) - lead;
+                if (e >= 0 && e < IMG) oc[e] = img[e];
+            }
+        }
+#endif
+        lds_barrier();   // the image is free for the next clip
+        STFT3_STAMP(7);
+#ifdef COUGH_K1_STAMPS
+        ++iter_no;
+#endif
+        if (clip_n >= n_clips) break;
+        clip = clip_n;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Spectral contrast + centroid rows (AudioPreprocessor.extract_spectral_contrast, preprocessing.py:242-303), out of
@@ -323,9 +581,36 @@ namespace {
 
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream) {
-    const dim3 grid(((n_clips + 7) / 8) * 8 * NCHUNK), block(THREADS);   // id = (slab * NCHUNK + chunk) * 8 + clip % 8
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const float* win = full ? v.win_full : v.win;
+    static const bool use_v1 = getenv("COUGH_STFT_V1") != nullptr;   // A/B only: the non-persistent register-staged kernel
+    if (!use_v1) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const dim3 grid3(n_clips < cus ? n_clips : cus), block3(THREADS3);   // one persistent workgroup per CU
+#define COUGH_STFT3_LAUNCH(F, M)                                                                                         \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            COUGH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stft3_kernel<F, M>),                       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS3_TOTAL));           \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((stft3_kernel<F, M>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win,     \
+                           v.tw256, v.tw512, n_clips);                                                                   \
+    } while (0)
+        if (full && mag) COUGH_STFT3_LAUNCH(true, true);
+        else if (full) COUGH_STFT3_LAUNCH(true, false);
+        else if (mag) COUGH_STFT3_LAUNCH(false, true);
+        else COUGH_STFT3_LAUNCH(false, false);
+#undef COUGH_STFT3_LAUNCH
+        COUGH_HIP_CHECK(hipGetLastError());
+        return COUGH_OK;
+    }
+    const dim3 grid(((n_clips + 7) / 8) * 8 * NCHUNK), block(THREADS);   // id = (slab * NCHUNK + chunk) * 8 + clip % 8
 #define COUGH_STFT_LAUNCH(F, M)                                                                              \
     hipLaunchKernelGGL((stft_kernel<F, M>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_spec, win, \
                        v.tw256, v.tw512, n_clips)
@@ -339,6 +624,12 @@ int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, flo
 }
 
 }  // namespace cough
+
+#ifdef COUGH_K1_STAMPS
+extern "C" int cough_debug_set_stft_stamp_buffer(void* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_stft_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_spec,
                                  int n_clips, int flags, void* stream) {
