@@ -302,13 +302,23 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
                 const int i = it * 64 + ln;   // 16-byte piece
                 if (i < GSPAN / 4) glds16(xc + s0 + 4 * i, myw_lds + it * 1024);
             }
-        } else {   // reflect padding of torch.stft(center=True): per-lane source addresses, one dword each
-#pragma unroll
-            for (int it = 0; it < (GSPAN + 63) / 64; ++it) {
-                const int i = it * 64 + ln;
-                int sidx = s0 + i;
-                sidx = sidx < 0 ? -sidx : (sidx >= NS ? 2 * (NS - 1) - sidx : sidx);
-                if (i < GSPAN) glds4(xc + sidx, myw_lds + it * 256);
+        } else {   // groups 0, 24, 25: reflect padding of torch.stft(center=True)
+            // the in-range part of the span still moves as 16-byte pieces (span start and clip length are multiples
+            // of 4 samples); only the reflected samples need per-lane source addresses, one dword each.  Group 25
+            // holds frame 100 alone: its first 512 samples are enough
+            const int lo = s0 < 0 ? -s0 : 0, hi = NS - s0 < GSPAN ? NS - s0 : GSPAN;   // direct samples: [lo, hi)
+            const int need = g == NGROUP - 1 ? NFFT : GSPAN;
+#pragma unroll 1
+            for (int p0 = lo / 4; p0 < (hi < need ? hi : need) / 4; p0 += 64) {
+                const int pc = p0 + ln;
+                if (4 * pc < hi) glds16(xc + s0 + 4 * pc, myw_lds + p0 * 16);
+            }
+#pragma unroll 1
+            for (int i0 = 0; i0 < lo; i0 += 64) glds4(xc - (s0 + i0 + ln), myw_lds + i0 * 4);   // lo is a multiple of 64
+#pragma unroll 1
+            for (int i0 = hi; i0 < need; i0 += 64) {                                             // so is hi
+                const int i = i0 + ln;
+                if (i < need) glds4(xc + 2 * (NS - 1) - (s0 + i), myw_lds + i0 * 4);
             }
         }
     };
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
     int iter_no = 0;
 #endif
 
+    bool first = true;
     while (true) {
         STFT3_STAMP(0);
         const long long clip_n = clip + gridDim.x;
@@ -384,6 +395,9 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             auto put = [&](int bin, float pwr4) {   // pwr4 = |2X|^2
                 col[bin * NFRAMES] = MAG ? 0.5f * sqrtf(pwr4) : 0.25f * pwr4;
             };
+            // the previous clip's flush has read the image: that barrier sits HERE, not behind the flush, so a wave
+            // that finished flushing early is already through the window / first radix-16 / transposes of this clip
+            if (rd == 0 && !first) lds_barrier();
             if (FPW * g + fsub < NFRAMES) {   // idle sub-frames of the last group store nothing
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
@@ -418,7 +432,11 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
 #pragma unroll
             for (int it = 0; it < (IMG_PIECES + THREADS3 - 1) / THREADS3; ++it) {
                 const int p = tid + THREADS3 * it;
+                #ifdef COUGH_STFT_NT_STORE
+                if (p > 0 && p < last) __builtin_nontemporal_store(src[p], dst + p);
+#else
                 if (p > 0 && p < last) dst[p] = src[p];
+#endif
             }
             if (tid < 8) {   // element e of the first (tid < 4) or last piece
                 const int e = (tid < 4 ? 0 : 4 * last) + (tid & 3) - lead;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             }
         }
 #endif
-        lds_barrier();   // the image is free for the next clip
+        first = false;
         STFT3_STAMP(7);
 #ifdef COUGH_K1_STAMPS
         ++iter_no;
