@@ -44,16 +44,16 @@ sys.path.insert(0, ROOT)
 BYTES_PER_CLIP = 64000 + 36360          # featurise: waveform read + (90,101) f32 written
 BYTES_PER_CLIP_STFT = 64000 + 103828    # STFT stage alone: waveform read + (257,101) f32 power written
 # featurise + stem fused: waveform read + the stem's (22,25,32) output written -- bf16 (plain bf16) or f32 (bf16x3)
-BYTES_PER_CLIP_FUSED = {"bf16": 64000 + 35200, "bf16x3": 64000 + 70400}
+BYTES_PER_CLIP_FUSED = {"bf16_approx": 64000 + 35200, "bf16x3": 64000 + 70400}
 FLOP_PER_CLIP = 42865600                # 2 * 21 432 800 MAC of the classifier
 FLOP_PER_CLIP_NO_STEM = 35668480        # minus the stem's 32*45*51*49 MAC (it runs inside the featurise kernel)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
-MFMA_PER_PRODUCT = {"bf16": 1, "bf16x3": 3, "fp32": 1}
+MFMA_PEAK_TFLOPS = {"bf16_approx": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+MFMA_PER_PRODUCT = {"bf16_approx": 1, "bf16x3": 3, "fp32": 1}
 DTYPE_LABEL = {
     "bf16x3": "bf16x3: split-bf16 MFMA (feature image, activations and BN-folded weights as hi+lo bf16 pairs, 3 "
               "v_mfma_f32_32x32x16_bf16 per k-step, f32 accumulate, f32 activations in HBM); featuriser f32",
-    "bf16": "bf16 (approximate mode): single-bf16 MFMA operands incl. the stem's feature image, bf16 activations, "
+    "bf16_approx": "bf16 (approximate mode): single-bf16 MFMA operands incl. the stem's feature image, bf16 activations, "
             "f32 accumulate; featuriser f32",
     "fp32": "f32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); featuriser f32",
 }
@@ -65,7 +65,7 @@ def measured_traffic(batch: int, variant: str):
     tools/pmc_to_json.py; FETCH_SIZE doubled per the gfx950 calibration).  PMC cannot be collected from
     inside this process, so the figure is read from profiles/ and only used when the batch matches.
     ``variant``: "k1" (featurise alone), "k1_fused_bf16" or "k1_fused_bf16x3"."""
-    path = os.path.join(ROOT, "profiles", {"k1": "r01_k1_pmc.json", "k1_fused_bf16": "r01_k1_fused_pmc.json",
+    path = os.path.join(ROOT, "profiles", {"k1": "r01_k1_pmc.json", "k1_fused_bf16_approx": "r01_k1_fused_pmc.json",
                                            "k1_fused_bf16x3": "r02_k1_fused_x3_pmc.json"}[variant])
     try:
         with open(path) as f:
@@ -189,7 +189,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4096, help="clips per rank per step")
-    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16x3"), choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("COUGH_BENCH_DTYPE", "bf16x3"), choices=["bf16x3", "bf16_approx", "fp32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--featurize-only", action="store_true", help="time K1 alone (BASELINE configs[1])")
     ap.add_argument("--rotate", type=int, default=3, help="distinct device-resident input batches the steps cycle over")
@@ -256,7 +256,7 @@ def main():
     model.to(dev).eval()
     feats = torch.empty((B, 90, 101), dtype=torch.float32, device=dev)
     pipe = cda.CoughPipeline(pre, model)
-    fused = args.dtype in ("bf16", "bf16x3") and not args.featurize_only   # the stem runs inside the featurise kernel
+    fused = args.dtype in ("bf16_approx", "bf16x3") and not args.featurize_only   # the stem runs inside the featurise kernel
     # every rank ends up with every clip's logits: the steps' logits are exchanged in buckets of --gather-every steps,
     # one all-gather per bucket on RCCL's stream while the next bucket is computed
     publisher = BucketedLogitsGather(B, args.gather_every, dev) if dist else None

@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=20.0)
-    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "bf16_approx", "fp32"])
     ap.add_argument("--stagger", action="store_true", help="de-phase the streams so windows complete on every tick")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

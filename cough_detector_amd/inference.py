@@ -153,7 +153,7 @@ def main(argv=None):
     parser.add_argument("--input", type=str, default=None,
                         help=".npy file with a 16 kHz mono float32 stream (default: a synthetic stream)")
     parser.add_argument("--seconds", type=float, default=10.0, help="Length of the synthetic stream")
-    parser.add_argument("--compute-dtype", type=str, default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    parser.add_argument("--compute-dtype", type=str, default="fp32", choices=["fp32", "bf16x3", "bf16_approx"],
                         help="classifier arithmetic (fp32 = exact-f32 MFMA; bf16x3 = split-bf16, the throughput mode)")
     args = parser.parse_args(argv)
     if args.list_devices:

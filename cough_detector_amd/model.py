@@ -117,9 +117,9 @@ class CoughDetectorResidual(nn.Module):
       values hi + lo (16 significant bits) and every k-step is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) into an
       f32 accumulator; activations are f32 in HBM.  Logits stay within 1e-3 of the f32 reference at a trained
       head's scale (measured 7e-5 on the goldens).  The throughput dtype of ``bench.py``.
-    * ``"bf16"``   single bf16 operands and bf16 activations (stem included), f32 accumulate: fastest, but
+    * ``"bf16_approx"`` single bf16 operands and bf16 activations (stem included), f32 accumulate: fastest, but
       APPROXIMATE -- logit error ~2 % of the class-margin spread (5.5e-2 on the goldens), outside the 1e-3
-      tolerance.
+      tolerance.  ``"bf16"`` is a deprecated alias that emits a ``UserWarning`` saying so.
     """
 
     def __init__(self, n_mels: int = 64, num_classes: int = 2, in_channels: int = 1,
@@ -131,9 +131,8 @@ class CoughDetectorResidual(nn.Module):
         if len(channels) < 2 or len(channels) > 17 or any(c < 1 or c > 1024 for c in channels):
             raise ValueError("CoughDetectorResidual: channels must be 2..17 values in 1..1024")
         self.channels = channels          # (32, 64, 128): the fused kernels; any other tuple: the exact-f32 kernels
-        if compute_dtype not in ("fp32", "bf16", "bf16x3", "_direct"):
-            raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
-        self.compute_dtype = compute_dtype            # what was asked for; ``effective_dtype`` is what runs
+        # what was asked for ('bf16' = deprecated alias of 'bf16_approx', warns); ``effective_dtype`` is what runs
+        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16x3", "bf16_approx", "_direct"))
         self._warned_fallback = set()
         self.conv1 = nn.Sequential(nn.Conv2d(in_channels, channels[0], 7, stride=2, padding=3),
                                    nn.BatchNorm2d(channels[0]), nn.ReLU(), nn.MaxPool2d(2))
@@ -327,9 +326,9 @@ class _ConvStackNet(nn.Module):
     subclasses describe their blocks (``_describe``) in terms of their own state_dict keys."""
 
     def _init_native(self, compute_dtype: str):
-        if compute_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
-        self.compute_dtype = compute_dtype
+        # "fp32" is the parity-grade mode of the conv-stack nets; their single-bf16 mode is approximate and has to be
+        # asked for by that name ('bf16' = deprecated alias, warns); there is no split-bf16 path for them
+        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16_approx"))
         self._handle: Optional[C.c_void_p] = None
         self._handle_key = None
         self._tensors = None

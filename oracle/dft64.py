@@ -77,3 +77,43 @@ def features(x: np.ndarray) -> np.ndarray:
     zp = np.concatenate([z[:, :1], z, z[:, -1:]], axis=1)
     delta = (zp[:, 2:] - zp[:, :-2]) / 2.0
     return np.concatenate([mel_n, z, delta], axis=0)
+
+
+def resample_direct(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                    rolloff: float = 0.99) -> np.ndarray:
+    """Band-limited interpolation by DIRECT evaluation of the published ``sinc_interp_hann`` formula (what
+    ``torchaudio.functional.resample`` implements as a polyphase FIR), float64, no polyphase table, no strided
+    convolution: output sample m sits at input position p = m * orig / new and
+
+        y[m] = sum_n x[n] * (f_c / orig) * sinc(pi * tau) * cos^2(pi * tau / (2 * lpw)),   tau = f_c * (n - p) / orig,
+
+    over the taps with |tau| < lpw (lpw = 6 zero crossings), f_c = rolloff * min(orig, new) in units where the rates
+    are reduced by their gcd; samples outside [0, N) are zero; ceil(N * new / orig) outputs."""
+    import math
+    x = np.asarray(x, dtype=np.float64)
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    fc = min(orig, new) * rolloff
+    n_out = int(math.ceil(len(x) * new / orig))
+    half = lowpass_filter_width * orig / fc                      # the window's half-width in input samples
+    y = np.zeros(n_out)
+    for m in range(n_out):
+        p = m * orig / new
+        lo, hi = int(math.floor(p - half)) - 1, int(math.ceil(p + half)) + 1
+        n = np.arange(max(lo, 0), min(hi, len(x) - 1) + 1)
+        tau = fc * (n - p) / orig
+        keep = np.abs(tau) < lowpass_filter_width
+        tau, n = tau[keep], n[keep]
+        s = np.where(tau == 0.0, 1.0, np.sin(np.pi * tau) / np.where(tau == 0.0, 1.0, np.pi * tau))
+        y[m] = np.sum(x[n] * s * np.cos(np.pi * tau / (2 * lowpass_filter_width)) ** 2) * (fc / orig)
+    return y
+
+
+def spectral_centroid_direct(x: np.ndarray, sample_rate: int = SR) -> np.ndarray:
+    """Centroid of the magnitude spectrogram taken with a periodic Hann(512) window (torchaudio's SpectralCentroid
+    default window = n_fft), float64: sum_k f_k |X_k| / sum_k |X_k|, f_k = k * sr / 512.  (T,)"""
+    n = np.arange(N_FFT, dtype=np.float64)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)
+    mag = np.abs(np.fft.rfft(frames(x) * w[None, :], axis=1))                 # (T, 257)
+    f = np.arange(N_FFT // 2 + 1) * (sample_rate / N_FFT)
+    return (mag * f[None, :]).sum(axis=1) / mag.sum(axis=1)

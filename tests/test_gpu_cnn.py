@@ -35,7 +35,7 @@ def test_fp32_matches_reference_goldens(cnn_golden, kind):
     assert float((probs.cpu() - vec["probs"]).abs().max()) < 1e-4      # trained-scale head: logits agree to ~1e-4
 
 
-# compute_dtype="bf16" of the conv-stack nets is a fast APPROXIMATE mode (single bf16 operands, bf16 activations): on a
+# compute_dtype="bf16_approx" of the conv-stack nets is a fast APPROXIMATE mode (single bf16 operands, bf16 activations): on a
 # trained-scale head its logit error is a few percent of the class-margin spread, outside LOGIT_TOL.  The parity-grade
 # mode of these two classifiers is "fp32" (tests above / below at 1e-4 .. 1e-3).
 BF16_REL = 0.12        # approximate mode: bound on max |class-margin error| / margin spread (and on |logit error| / max |logit|)
@@ -50,7 +50,7 @@ def _approx_ok(got, ref):
 @pytest.mark.parametrize("kind", KINDS)
 def test_bf16_is_an_approximate_mode(cnn_golden, kind):
     sd, vec = cnn_golden[kind]
-    m = _model(kind, sd, "bf16")
+    m = _model(kind, sd, "bf16_approx")
     x = cnn_golden["x"].cuda()
     logits = m(x).cpu()
     lerr = float((logits - vec["logits"]).abs().max())
@@ -64,7 +64,7 @@ def test_bf16_is_an_approximate_mode(cnn_golden, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("dtype,tol", [("fp32", LOGIT_TOL), ("bf16", None)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", LOGIT_TOL), ("bf16_approx", None)])
 def test_fresh_features_ragged_batch_and_other_sizes(cnn_golden, kind, dtype, tol):
     """A batch that is not a multiple of any tile (37 clips), real featuriser output, and a second image size
     (the networks are fully convolutional: global mean at the end)."""
@@ -91,6 +91,10 @@ def test_fresh_features_ragged_batch_and_other_sizes(cnn_golden, kind, dtype, to
 
 def test_interface_errors(cnn_golden):
     sd, _ = cnn_golden["small"]
+    with pytest.warns(UserWarning, match="APPROXIMATE single-bf16 mode"):      # nobody gets it without being told
+        assert cda.create_model("small", compute_dtype="bf16").compute_dtype == "bf16_approx"
+    with pytest.raises(ValueError, match="compute_dtype must be one of 'fp32', 'bf16_approx'"):
+        cda.create_model("standard", compute_dtype="bf16x3")                      # no split-bf16 path for these nets
     m = _model("small", sd, "fp32")
     with pytest.raises(ValueError, match="expected input"):
         m(torch.zeros(2, 90, 101))

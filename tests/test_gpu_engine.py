@@ -151,7 +151,7 @@ def test_graph_replay_equals_eager_launches():
     streams = np.stack([synth.make_stream(40 + s, 4.0) for s in range(S)])
     runs = []
     for use_graphs in (True, False):
-        model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
         model.load_state_dict(sd)
         now = {"t": 0.0}
         det = MultiStreamDetector(model, S, confidence_threshold=0.5, clock=lambda: now["t"], use_graphs=use_graphs)

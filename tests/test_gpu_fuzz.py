@@ -98,7 +98,7 @@ def test_stream_detector_reset_and_chunk_length_change():
     streams = np.stack([synth.make_stream(60 + s, 5.0) for s in range(4)])
     out = []
     for use_graphs in (True, False):
-        m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
         m.load_state_dict(sd)
         det = MultiStreamDetector(m, 4, confidence_threshold=2.0, clock=lambda: 0.0, use_graphs=use_graphs)
         log = []

@@ -139,7 +139,7 @@ def test_model_state_dict_contract(resnet_golden):
 def test_conv_stack_models_take_the_reference_state_dicts(cnn_golden):
     for kind, n_params in (("standard", 421954), ("small", 21122)):
         sd, _ = cnn_golden[kind]
-        m = cda.create_model(kind, n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+        m = cda.create_model(kind, n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
         assert set(m.state_dict().keys()) == set(sd.keys())
         m.load_state_dict(sd)                                                # strict
         assert cda.count_parameters(m) == n_params
@@ -201,4 +201,6 @@ def test_effective_dtype_reports_the_kernels_that_run():
     wide = cda.CoughDetectorResidual(channels=(16, 24, 40), compute_dtype="bf16x3")
     assert wide.effective_dtype() == "fp32" and wide.compute_dtype == "bf16x3"
     assert cda.create_model("residual", compute_dtype="fp32").effective_dtype(33, 77) == "fp32"
-    assert cda.create_model("residual", compute_dtype="bf16").effective_dtype() == "bf16"
+    assert cda.create_model("residual", compute_dtype="bf16_approx").effective_dtype() == "bf16_approx"
+    with pytest.warns(UserWarning, match="APPROXIMATE single-bf16 mode"):      # the old name still works, loudly
+        assert cda.create_model("residual", compute_dtype="bf16").compute_dtype == "bf16_approx"

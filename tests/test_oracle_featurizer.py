@@ -222,3 +222,73 @@ def test_spectral_contrast_restatement_band_edges_and_nan_rule():
     assert f.shape == (1, 64 + 39 + 4, 101)
     assert torch.equal(f[:, -4:], F.extract_spectral_contrast(w, 3))
     assert F.extract_features(w, use_mfcc=False).shape == (1, 64, 101)
+
+
+# ---- third-party / independent checks of the 8f oracles that no reference fixture pins (torchaudio is absent) ----
+@pytest.mark.parametrize("orig", [44100, 22050, 48000, 8000])
+def test_resampler_against_direct_float64_evaluation_of_the_published_formula(orig):
+    """``oracle.featurizer.resample`` (polyphase kernel table + strided conv1d, the way T.Resample builds it,
+    /root/reference/src/preprocessing.py:146-183) vs ``dft64.resample_direct`` (one sum per output sample straight
+    from the sinc_interp_hann formula, float64, shares no code): agreement to float32 rounding means kernel table,
+    phase order, padding, stride and output length are all right."""
+    from oracle import dft64
+    rng = np.random.default_rng(orig)
+    n = 3000
+    x = (0.4 * np.sin(2 * np.pi * 440.0 * np.arange(n) / orig) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    got = F.resample(torch.from_numpy(x)[None], orig, 16000)[0].numpy()
+    want = dft64.resample_direct(x, orig, 16000)
+    assert got.shape == want.shape == (int(np.ceil(n * 16000 / orig)),)
+    assert np.abs(got - want).max() < 2e-6, np.abs(got - want).max()
+
+
+def test_resampler_kernel_table_properties():
+    """The table itself against closed-form facts: every phase sums to ~1 when down-sampling (DC gain of the
+    low-pass, <= 1e-3 ripple from the truncated sinc), phase 0 at zero delay is its own peak, and the table equals the
+    direct formula tap by tap."""
+    import math
+    for orig, new in ((44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000)):
+        k, width, o, nw = F.sinc_resample_kernel(orig, new)
+        k = k[:, 0].double().numpy()                                            # (new, K)
+        assert k.shape == (nw, 2 * width + o)
+        fc = min(o, nw) * 0.99
+        idx = np.arange(-width, width + o)
+        for ph in (0, nw // 3, nw - 1):
+            tau = np.clip(fc * (idx / o - ph / nw), -6, 6)
+            want = np.where(tau == 0, 1.0, np.sin(np.pi * tau) / np.where(tau == 0, 1.0, np.pi * tau)) * \
+                np.cos(np.pi * tau / 12) ** 2 * (fc / o)
+            assert np.abs(k[ph] - want).max() < 1e-7
+        if o >= nw:                                                             # low-pass at the NEW Nyquist: unit DC gain
+            assert np.abs(k.sum(axis=1) - 1.0).max() < 2e-3
+        assert int(np.argmax(k[0])) == width
+
+
+def test_resampler_against_scipy_polyphase_on_a_band_limited_signal():
+    """Code the builder did not write: ``scipy.signal.resample_poly`` (Kaiser-windowed FIR, a different filter, so only
+    band-limited content far from both Nyquists can agree): a 300 Hz + 1.2 kHz tone pair, interior samples, 1e-3."""
+    from scipy.signal import resample_poly
+    orig, n = 48000, 9600
+    t = np.arange(n) / orig
+    x = (0.5 * np.sin(2 * np.pi * 300 * t) + 0.25 * np.sin(2 * np.pi * 1200 * t + 0.3)).astype(np.float32)
+    got = F.resample(torch.from_numpy(x)[None], orig, 16000)[0].numpy()
+    want = resample_poly(x.astype(np.float64), 1, 3)
+    tt = np.arange(len(got)) / 16000.0
+    exact = 0.5 * np.sin(2 * np.pi * 300 * tt) + 0.25 * np.sin(2 * np.pi * 1200 * tt + 0.3)
+    inner = slice(200, len(got) - 200)
+    assert np.abs(got[inner] - exact[inner]).max() < 1e-3                       # band-limited interpolation is exact
+    assert np.abs(got[inner] - want[inner]).max() < 2e-3
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5])
+def test_spectral_centroid_against_float64_numpy(seed):
+    """``oracle.featurizer.spectral_centroid`` (torch.stft path, float32) vs a float64 numpy one-liner on independently
+    framed Hann(512) magnitudes (dft64.spectral_centroid_direct)."""
+    from oracle import dft64
+    x = synth.make_clip(seed)
+    got = F.spectral_centroid(torch.from_numpy(x)[None])[0].numpy()
+    want = dft64.spectral_centroid_direct(x)
+    assert got.shape == want.shape == (101,)
+    assert np.abs(got - want).max() / 8000.0 < 2e-6
+    # known answer: a pure bin-centred tone has its centroid at the tone (leakage of Hann(512) is symmetric)
+    tone = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0).astype(np.float32)
+    c = F.spectral_centroid(torch.from_numpy(tone)[None])[0].numpy()
+    assert np.abs(c[5:95] - 1000.0).max() < 0.5

@@ -34,7 +34,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--kinds", default="residual,standard,small")
-ap.add_argument("--dtypes", default="bf16,fp32")
+ap.add_argument("--dtypes", default="bf16_approx,fp32")
 args = ap.parse_args()
 bound_torch_threads()
 dev = torch.device("cuda:0")

@@ -16,7 +16,7 @@ B = 4096
 dev = torch.device("cuda:0")
 pre = cda.AudioPreprocessor(device="cuda", use_pcen=False, use_pre_emphasis=False, use_delta_delta=False,
                             use_spectral_contrast=False)
-model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
 model.load_state_dict(synth.random_state_dict(seed=3))
 model.to(dev).eval()
 pipe = cda.CoughPipeline(pre, model)

@@ -7,7 +7,7 @@ from cough_detector_amd import synth
 from cough_detector_amd.streaming import MultiStreamDetector
 torch.set_num_threads(4)
 S=64
-model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
 model.load_state_dict(synth.random_state_dict(seed=3))
 det = MultiStreamDetector(model, S, confidence_threshold=0.7, clock=lambda: 0.0)
 audio = torch.from_numpy(np.stack([synth.make_stream(100+s, 30.0) for s in range(S)])).pin_memory()

@@ -17,7 +17,7 @@ x, ref = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["logits"])
 margin = (ref[:, 1] - ref[:, 0])
 print(f"goldens: {len(ref)} clips, margin std {margin.std():.3f}, min |margin| {margin.abs().min():.4f}, "
       f"max |logit| {ref.abs().max():.3f}")
-for dtype in sys.argv[1:] or ["fp32", "bf16x3", "bf16"]:
+for dtype in sys.argv[1:] or ["fp32", "bf16x3", "bf16_approx"]:
     m = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype=dtype)
     m.load_state_dict(sd)
     m.cuda().eval()

@@ -13,7 +13,7 @@ _lib.LIB_PATH = LIB
 import cough_detector_amd as cda
 lib = _lib.load()
 B = 4096
-model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16")
+model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16_approx")
 model.load_state_dict(synth.random_state_dict(seed=3)); model.cuda()
 x = torch.rand(B, 1, 90, 101, device="cuda")
 model(x)
