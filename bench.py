@@ -60,21 +60,24 @@ DTYPE_LABEL = {
 SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
 
-def measured_traffic(batch: int, variant: str):
-    """HBM-side bytes per K1 launch from the committed rocprofv3 PMC passes (tools/pmc_k1.sh ->
-    tools/pmc_to_json.py; FETCH_SIZE doubled per the gfx950 calibration).  PMC cannot be collected from
-    inside this process, so the figure is read from profiles/ and only used when the batch matches.
-    ``variant``: "k1" (featurise alone), "k1_fused_bf16" or "k1_fused_bf16x3"."""
-    path = os.path.join(ROOT, "profiles", {"k1": "r01_k1_pmc.json", "k1_fused_bf16_approx": "r01_k1_fused_pmc.json",
-                                           "k1_fused_bf16x3": "r02_k1_fused_x3_pmc.json"}[variant])
-    try:
-        with open(path) as f:
-            p = json.load(f)
-        if p["clips_per_launch"] == batch:
-            return int(p["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        pass
-    return None, None
+def measured_pmc(batch: int, variant: str) -> dict:
+    """The committed rocprofv3 PMC record of the K1 launch (tools/pmc_k1.sh -> tools/pmc_to_json.py: HBM-side bytes
+    with FETCH_SIZE doubled per the gfx950 calibration, and the VALU-issue share from the SQ pass).  PMC cannot be
+    collected from inside this process, so the figures are read from profiles/ and only used when the batch matches.
+    ``variant``: "k1" (featurise alone), "k1_fused_bf16_approx" or "k1_fused_bf16x3"."""
+    names = {"k1": ["r01_k1_pmc.json"], "k1_fused_bf16_approx": ["r01_k1_fused_pmc.json"],
+             "k1_fused_bf16x3": ["r03_k1_fused_x3_pmc.json", "r02_k1_fused_x3_pmc.json"]}[variant]
+    for name in names:                                   # newest record first
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                p = json.load(f)
+            if p["clips_per_launch"] == batch:
+                p["source"] = os.path.relpath(path, ROOT)
+                return p
+        except (OSError, KeyError, ValueError):
+            pass
+    return {}
 
 
 def stft_stage(pre, batches, launches: int = 210) -> dict:
@@ -332,9 +335,15 @@ def main():
 
     if rank == 0:
         total_clips = sum(step_total)
-        k1_bytes = BYTES_PER_CLIP_FUSED[args.dtype] if fused else BYTES_PER_CLIP
+        # the featurise stage's algorithmic bytes are 64 000 read + 36 360 written per clip, fused or not.
+        # The fused kernel writes the stem's activation a1 instead of the feature image (bf16x3: 70 400 B of f32 per
+        # clip); that hand-off shows up in `traffic` (PMC), not in `achieved`.
+        k1_bytes = BYTES_PER_CLIP
         achieved = Bk * k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(Bk, ("k1_fused_" + args.dtype) if fused else "k1")
+        pmc = measured_pmc(Bk, ("k1_fused_" + args.dtype) if fused else "k1")
+        traffic, traffic_src = pmc.get("traffic_bytes_per_launch"), pmc.get("source")
+        if traffic is not None:
+            traffic = int(traffic)
         if args.featurize_only:
             workload = "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32"
         elif args.total_clips > 0:
@@ -363,8 +372,14 @@ def main():
             "roofline": {"kernel": f"featurize_kernel<stem fused, {args.dtype}> (K1+K2)" if fused else "featurize_kernel (K1)",
                          "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": round(k1_ms, 4),
-                         "algorithmic_bytes_per_launch": Bk * k1_bytes, "clips_per_launch": Bk},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": round(traffic / (Bk * k1_bytes), 3) if traffic else None,
+                         "ms_per_launch": round(k1_ms, 4),
+                         "algorithmic_bytes_per_launch": Bk * k1_bytes, "clips_per_launch": Bk,
+                         "bytes_moved_per_launch": Bk * (BYTES_PER_CLIP_FUSED[args.dtype] if fused else BYTES_PER_CLIP),
+                         # the roof that actually binds K1: VALU issue (PMC SQ_ACTIVE_INST_VALU / SIMD quad-cycle slots)
+                         "valu_issue_frac": pmc.get("valu_issue_frac"),
+                         "valu_insts_per_clip": pmc.get("valu_insts_per_clip")},
         }
         if not args.featurize_only and net_ms > 0:
             tf = Bk * (FLOP_PER_CLIP_NO_STEM if fused else FLOP_PER_CLIP) / (net_ms * 1e-3) / 1e12

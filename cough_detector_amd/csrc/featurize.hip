@@ -34,6 +34,8 @@
 
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "fft256.h"
 #include "internal.h"
@@ -59,7 +61,8 @@ struct FeatTables {
     float2 tw512[NBIN];       // W512^k
     int mel_start[NMEL];      // first bin of band m
     float mel_w[NMEL][MAXW];  // taps of band m from mel_start
-    float dct_t[NMFCC][NMEL]; // DCT-II ortho, [coeff][mel]
+    float dct_t[NMFCC + 1][NMEL];   // DCT-II ortho, [coeff][mel]; row 13 = zeros (the 7th, unused accumulator of the
+                                    // second thread half: keeps the DCT loop free of branches)
 };
 
 constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 4;   // 17408
@@ -373,12 +376,14 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (tt < NFRAMES) {
         const float* drow = &tb->dct_t[c0][0];
+        // seven coefficients for both halves (the second half's seventh is the table's zero row): no branch in the
+        // loop, so the wave-uniform coefficients arrive as s_load_dwordx8 blocks -- a conditional seventh coefficient
+        // made every one of its 64 products wait out a scalar load of its own
 #pragma unroll 8
         for (int m = 0; m < NMEL; ++m) {
             const float v = melbuf[m * NFRAMES + tt];
 #pragma unroll
-            for (int cc = 0; cc < 7; ++cc)
-                if (cc < nc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
+            for (int cc = 0; cc < 7; ++cc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
         }
     }
     K1_MARK("PHASE P2 mean / std / z-score");
@@ -612,6 +617,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     }
     for (int c = 0; c < NMFCC; ++c)
         for (int m = 0; m < NMEL; ++m) t.dct_t[c][m] = dct[m * NMFCC + c];
+    for (int m = 0; m < NMEL; ++m) t.dct_t[NMFCC][m] = 0.f;
 
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
@@ -682,6 +688,19 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
     const StemFuse none{nullptr, nullptr, nullptr, 0};
+#ifdef COUGH_EXP_OVERLAP
+    // diagnostic build only (tools/exp_coresident.py): claim more LDS than the kernel uses, so that fewer featurise
+    // workgroups fit a CU and a residual-block workgroup of another stream can sit beside them
+    if (stem && stem->x3 && getenv("COUGH_EXP_K1_LDS")) {
+        const size_t lds = size_t(atoi(getenv("COUGH_EXP_K1_LDS")));
+        COUGH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(featurize_kernel<false, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, lds, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
+        COUGH_HIP_CHECK(hipGetLastError());
+        return COUGH_OK;
+    }
+#endif
     if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);

@@ -1465,6 +1465,15 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
     if (can_fuse_stem(f, m)) {
         const Workspace w = carve(m, ws, n_clips, s);
         const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, w.a1, m->dtype == COUGH_DTYPE_BF16X3 ? 1 : 0};
+#ifdef COUGH_EXP_OVERLAP
+        // diagnostic build only (tools/exp_coresident.py): run one half of the pipeline (timing experiments on two streams)
+        const char* only = getenv("COUGH_EXP_ONLY");
+        if (only && only[0] == 'b') {   // "blocks": a1 is whatever an earlier launch left in this workspace
+            if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
+            return forward_impl<bf16_t>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
+        }
+        if (only && only[0] == 'k') return launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st);
+#endif
         if (int e = launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st)) return e;
         if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
         if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);

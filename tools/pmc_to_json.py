@@ -29,5 +29,12 @@ out = {"kernel": kern + "_kernel", "clips_per_launch": batch, "normalize": True,
        "traffic_bytes_per_launch": fetch_b + write_b,
        "algorithmic_bytes_per_launch": batch * bytes_per_clip,
        "traffic_over_algorithmic": (fetch_b + write_b) / (batch * bytes_per_clip)}
+# VALU-issue share, when the SQ pass is in the same directory: SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD
+# issues VALU work; the launch offers GRBM_GUI_ACTIVE / 8 XCDs cycles on each of 1024 SIMDs = that many / 4 quad-cycle slots
+if "SQ_ACTIVE_INST_VALU" in per and "GRBM_GUI_ACTIVE" in per:
+    slots = per["GRBM_GUI_ACTIVE"] / 8.0 * 1024 / 4.0
+    out["valu_issue_frac"] = round(per["SQ_ACTIVE_INST_VALU"] / slots, 4)
+if "SQ_INSTS_VALU" in per:
+    out["valu_insts_per_clip"] = round(per["SQ_INSTS_VALU"] / batch, 1)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "traffic_over_algorithmic")}))
