@@ -98,10 +98,19 @@ def stft_stage(pre, batches, launches: int = 210) -> dict:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / launches
     achieved = b * BYTES_PER_CLIP_STFT / (ms * 1e-3) / 1e9
-    return {"kernel": "stft_kernel (waveform -> 257x101 power spectrogram)", "bound": "hbm",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    traffic, src = None, None
+    try:                                                  # committed rocprofv3 PMC record of the same kernel
+        with open(os.path.join(ROOT, "profiles", "r03_stft_pmc.json")) as f:
+            p = json.load(f)
+        if p["clips_per_launch"] == b:
+            traffic, src = int(p["traffic_bytes_per_launch"]), "profiles/r03_stft_pmc.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"kernel": "stft3_kernel (waveform -> 257x101 power spectrogram; persistent, one 13-wave workgroup per CU)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),
-            "algorithmic_bytes_per_launch": b * BYTES_PER_CLIP_STFT}
+            "algorithmic_bytes_per_launch": b * BYTES_PER_CLIP_STFT, "traffic": traffic, "traffic_source": src,
+            "traffic_over_algorithmic": round(traffic / (b * BYTES_PER_CLIP_STFT), 3) if traffic else None}
 
 
 def cpu_baseline(budget_s: float) -> dict:

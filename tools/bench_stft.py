@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--magnitude", action="store_true")
 ap.add_argument("--full-window", action="store_true")
 ap.add_argument("--check", action="store_true", help="compare 64 clips with the CPU oracle first")
+ap.add_argument("--prewarm-s", type=float, default=0.6, help="untimed pre-warm (0 under rocprofv3 --pmc)")
 args = ap.parse_args()
 bound_torch_threads()
 dev = torch.device("cuda:0")
@@ -40,7 +41,7 @@ if args.check:
     err = ((got - ref).abs() / ref.abs().clamp_min(ref.abs().amax(dim=(1, 2), keepdim=True) * 1e-5)).max().item()
     print(f"check vs oracle (64 clips): max rel err {err:.2e}")
 t0 = time.perf_counter()
-while time.perf_counter() - t0 < 0.6:
+while time.perf_counter() - t0 < args.prewarm_s:
     for i in range(20):
         pre.spectrogram_batch(batches[i % 3], **kw)
     torch.cuda.synchronize()
