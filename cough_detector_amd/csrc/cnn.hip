@@ -343,6 +343,168 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_kernel(CnnLdsArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ split-bf16 blocks
+// cnn_conv_lds_x3_kernel: the LDS-image convolution above with every operand as a pair x = hi + lo of bf16 values
+// (hi = bf16(x), lo = bf16(x - hi): 16 significant bits) and three MFMAs per k-step, hi*hi + lo*hi + hi*lo, into one
+// f32 accumulator -- the scheme of resblock_x3.h, whose logits stay within 1e-3 of the f32 reference where single bf16
+// operands are 0.1-0.3 off.  Activations cross HBM as f32 (NHWC) and are split while they are staged into TWO swizzled
+// LDS images; weights arrive as (hi, lo) MFMA fragments [k-step][n-tile][2][64 lanes][8]; blockIdx.y selects a group
+// of NT 32-channel tiles (128 -> 256 channels: two groups).
+constexpr int CNN_X3_UNP = 24;   // 16-byte f32 pieces (4 channels) of the band per thread: 2 images <= 96 KB
+struct CnnX3Args {
+    const float* in;      // NHWC [B][H][W][CIN] f32
+    const bf16_t* wf;     // [9 * CIN / 16][ntot][2 = hi, lo][64][8]
+    const float* bias;
+    float* out;           // NHWC [B][OH][OW][32 * ntot] f32
+    int H, W, OH, OW;     // OH x OW: output size (pooled when POOL)
+    int band_rows;        // output rows per workgroup
+    int n_bands;          // workgroups per clip
+    int ntot;             // 32-channel tiles of the layer
+};
+
+template <int CIN, int NT, int MW, bool POOL>
+__global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
+    constexpr int CH = CIN / 8, QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.x / a.n_bands, band = blockIdx.x - clip * a.n_bands;
+    const int nt0 = blockIdx.y * NT, N = 32 * a.ntot;
+    const int o0 = band * a.band_rows;
+    const int orows = a.OH - o0 < a.band_rows ? a.OH - o0 : a.band_rows;
+    const int crow0 = S * o0, crows = S * orows;
+    const int Wb = a.W + 2, irows = crows + 2;
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem_raw);                       // hi image
+    bf16_t* img_lo = img + ((irows * Wb * CIN + 7) & ~7);                    // lo image (16-byte aligned)
+
+    // ---- stage: every 16-byte f32 piece (4 channels of one pixel) is requested before the first one is split ----
+    {
+        const float* src = a.in + (long long)clip * a.H * a.W * CIN;
+        const int total = irows * Wb * QP;
+        const float inv_wb = 1.0f / float(Wb);
+        float4 v[CNN_X3_UNP];
+        int dst[CNN_X3_UNP];
+#pragma unroll
+        for (int u = 0; u < CNN_X3_UNP; ++u) {
+            const int i = tid + u * 256;
+            const int q = i & (QP - 1), P = i / QP;
+            int rr = int(float(P) * inv_wb);
+            rr -= (rr * Wb > P);
+            rr += ((rr + 1) * Wb <= P);
+            const int cc = P - rr * Wb;
+            const int iy = crow0 - 1 + rr, ix = cc - 1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[u] = i < total ? swz_off<CIN>(P, q >> 1) + 4 * (q & 1) : -1;
+            if (i < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v[u] = *reinterpret_cast<const float4*>(src + ((long long)iy * a.W + ix) * CIN + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < CNN_X3_UNP; ++u)
+            if (dst[u] >= 0) {
+                uint2 hi, lo;
+                split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
+                *reinterpret_cast<uint2*>(img + dst[u]) = hi;
+                *reinterpret_cast<uint2*>(img_lo + dst[u]) = lo;
+            }
+    }
+    __syncthreads();
+
+    const int M = orows * a.OW * (POOL ? 4 : 1);
+    if (wave * MW * 32 >= M) return;               // whole wave beyond the band (no barrier follows)
+    int pix[MW];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        int m = (wave * MW + mt) * 32 + r;
+        if (m >= M) m = M - 1;
+        int y, x;
+        if constexpr (POOL) {
+            const int win = m >> 2, q = m & 3, py = win / a.OW, px = win - py * a.OW;
+            y = 2 * py + (q >> 1);
+            x = 2 * px + (q & 1);
+        } else {
+            y = m / a.OW;
+            x = m - y * a.OW;
+        }
+        pix[mt] = y * Wb + x;
+    }
+    f32x16 acc[MW][NT];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x16{0};
+
+    const bf16_t* wl = a.wf + (size_t(nt0) * 2) * 512 + lane * 8;
+    const size_t wstep = size_t(a.ntot) * 2 * 512;
+    constexpr int D = (NT <= 2) ? 4 : 2;
+    bf16x8 wring[D][NT][2], af[2][MW][2];
+    auto wload = [&](int s, bf16x8 (&dst)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            dst[nt][0] = *reinterpret_cast<const bf16x8*>(wl + size_t(s) * wstep + size_t(nt) * 1024);
+            dst[nt][1] = *reinterpret_cast<const bf16x8*>(wl + size_t(s) * wstep + size_t(nt) * 1024 + 512);
+        }
+    };
+    auto aload = [&](auto sc, int mt, bf16x8 (&dst)[2]) {
+        constexpr int s = decltype(sc)::value, tap = s / (CIN / 16), c16 = s % (CIN / 16), kh = tap / 3, kw = tap % 3;
+        const int off = swz_off<CIN>(pix[mt] + kh * Wb + kw, 2 * c16 + h);
+        dst[0] = *reinterpret_cast<const bf16x8*>(img + off);
+        dst[1] = *reinterpret_cast<const bf16x8*>(img_lo + off);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) wload(i, wring[i]);
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) aload(std::integral_constant<int, 0>{}, mt, af[0][mt]);
+    auto step = [&]<int s>() {
+        bf16x8 bw[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bw[nt][0] = wring[s % D][nt][0]; bw[nt][1] = wring[s % D][nt][1]; }
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            if constexpr (s + 1 < KSTEPS) aload(std::integral_constant<int, s + 1>{}, mt, af[(s + 1) & 1][mt]);
+            if constexpr (s + D < KSTEPS) {
+                if (mt == 0) wload(s + D, wring[s % D]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][1], bw[nt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][1], acc[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+        (step.template operator()<Ss>(), ...);
+    }(std::make_integer_sequence<int, KSTEPS>{});
+
+    // epilogue: register `reg` of lane (r, h) is GEMM row (reg & 3) + 8 * (reg >> 2) + 4 * h of the tile, column r
+    float* o = a.out + ((long long)clip * a.OH + o0) * a.OW * N;
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        const int m0 = (wave * MW + mt) * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nt0 + nt) * 32 + r;
+            const float bn = a.bias[n];
+            if constexpr (POOL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int win = (m0 >> 2) + 2 * g + h;
+                    const float v = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]),
+                                          fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
+                    if (win * 4 < M) o[(long long)win * N + n] = fmaxf(v + bn, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int mo = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (mo < M) o[(long long)mo * N + n] = fmaxf(acc[mt][nt][reg] + bn, 0.f);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ head
 // one workgroup per clip: thread c < C averages channel c; thread j < HID forms hidden unit j; wave 0 the logits
 template <typename T>
@@ -411,7 +573,8 @@ struct cough_cnn {
         float* d_b;
         int ktot;       // row pitch of d_w: ks*ks*cin, padded to a multiple of 64 for the LDS-staged bf16 GEMM
         bool gemm;      // bf16, cin % 32 == 0, cout % 64 == 0: conv_gemm_bf16_kernel
-        cough::bf16_t* d_wfrag;   // bf16 (16->32), (32->64), (64->128) blocks: MFMA fragments for cnn_conv_lds_kernel
+        cough::bf16_t* d_wfrag;   // bf16 (16->32), (32->64), (64->128) blocks: MFMA fragments for cnn_conv_lds_kernel;
+                                  // bf16x3: (hi, lo) fragments of every block after the first for cnn_conv_lds_x3_kernel
     };
     int dtype;
     size_t esize;
@@ -444,6 +607,21 @@ int cnn_upload(void** dst, const std::vector<T>& v) {
     return COUGH_OK;
 }
 
+// output rows per workgroup of the split-bf16 LDS-image convolution (0: the layer does not fit, use the f32 kernel):
+// the kernel's tile shape must exist (cin -> cout pairs it is instantiated for), the band's GEMM rows must fit
+// 4 waves x MW tiles and its two bf16 images CNN_X3_UNP x 256 sixteen-byte pieces
+inline int x3_band(const cough_cnn::Layer& l, const CnnShape& s, int in_w) {
+    const int nt = l.cout >= 128 ? 4 : l.cout / 32;
+    const bool shape_ok = (l.cin == 16 && nt == 1) || (l.cin == 32 && nt == 2) || (l.cin == 64 && nt == 4) ||
+                          (l.cin == 128 && nt == 4);
+    if (!shape_ok) return 0;
+    const int mw = (l.cin == 64 || l.cin == 128) ? 2 : 4, per_out = l.pool == 2 ? 4 : 1;
+    int band = (4 * mw * 32) / (per_out * s.w);
+    if (band > s.h) band = s.h;
+    while (band >= 1 && size_t((l.pool == 2 ? 2 : 1) * band + 2) * (in_w + 2) * (l.cin / 4) > size_t(CNN_X3_UNP) * 256) --band;
+    return band;
+}
+
 template <typename T>
 int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int W, float* d_logits, float* d_probs,
                      int* d_preds, char* ws, hipStream_t st, int tap_layer, float* d_tap) {
@@ -467,7 +645,7 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
             else
                 hipLaunchKernelGGL((cnn_first_kernel<T, false>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
                                    static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
-        } else if (l.d_wfrag) {
+        } else if (l.d_wfrag && sizeof(T) == 2) {
             if constexpr (sizeof(T) == 2) {
                 // band of output rows per workgroup: 4 waves x MW tiles x 32 GEMM rows (x4 rows per output when pooled)
                 const int mw = l.cin == 64 ? 2 : 4, per_out = l.pool == 2 ? 4 : 1;
@@ -506,6 +684,26 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
                 else if (nt == 4) hipLaunchKernelGGL((conv_gemm_bf16_kernel<4, false>), grid, dim3(256), 0, st, a);
                 else if (l.pool == 2) hipLaunchKernelGGL((conv_gemm_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((conv_gemm_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
+            }
+        } else if (sizeof(T) == 4 && m->dtype == COUGH_DTYPE_BF16X3 && l.d_wfrag && x3_band(l, s, cw) >= 1) {
+            if constexpr (sizeof(T) == 4) {
+                // split-bf16 LDS-image convolution: band of output rows per workgroup, as many as 4 waves x MW tiles cover
+                // and as two band images of <= 96 KB hold
+                const int band = x3_band(l, s, cw), n_bands = (s.h + band - 1) / band;
+                const size_t lds = (size_t((l.pool == 2 ? 2 : 1) * band + 2) * (cw + 2) * l.cin * 2 + 15) / 16 * 16 * 2;
+                CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32};
+                const int nt = l.cout >= 128 ? 4 : l.cout / 32;
+                const dim3 grid((unsigned)(n * n_bands), (unsigned)(l.cout / (32 * nt)));
+#define COUGH_X3_LAUNCH(CIN, NT, MW)                                                                                 \
+    do {                                                                                                             \
+        if (l.pool == 2) hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, true>), grid, dim3(256), lds, st, a);   \
+        else hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, false>), grid, dim3(256), lds, st, a);              \
+    } while (0)
+                if (l.cin == 16) COUGH_X3_LAUNCH(16, 1, 4);
+                else if (l.cin == 32) COUGH_X3_LAUNCH(32, 2, 4);
+                else if (l.cin == 64) COUGH_X3_LAUNCH(64, 4, 2);
+                else COUGH_X3_LAUNCH(128, 4, 2);
+#undef COUGH_X3_LAUNCH
             }
         } else {
             CnnConvArgs<T> a{};
@@ -565,10 +763,11 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
     using namespace cough;
     COUGH_REQUIRE(out && w && w->blocks && w->fc1_w && w->fc1_b && w->fc2_w && w->fc2_b, COUGH_EINVAL,
                   "cough_cnn_create: NULL argument");
-    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16, COUGH_EINVAL, "cough_cnn_create: unknown dtype %d", dtype);
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_BF16X3, COUGH_EINVAL,
+                  "cough_cnn_create: unknown dtype %d", dtype);
     COUGH_REQUIRE(w->n_blocks >= 2 && w->n_blocks <= 16, COUGH_EUNSUPPORTED, "cough_cnn_create: %d blocks (need 2..16)", w->n_blocks);
     COUGH_REQUIRE(w->hidden >= 1 && w->hidden <= 256, COUGH_EUNSUPPORTED, "cough_cnn_create: hidden = %d (need 1..256)", w->hidden);
-    const int chunk = dtype == COUGH_DTYPE_BF16 ? 16 : 8;
+    const int chunk = dtype == COUGH_DTYPE_FP32 ? 8 : 16;
     for (int i = 0; i < w->n_blocks; ++i) {
         const cough_cnn_block& bk = w->blocks[i];
         const cough_conv_bn& p = bk.conv;
@@ -647,11 +846,45 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
                                 f2bf_host(float(wd[size_t(32 * t + (lane & 31)) * K + 16 * st + 8 * (lane >> 5) + jj]));
             err = cnn_upload(reinterpret_cast<void**>(&l.d_wfrag), wfr);
         }
+        if (!err && i > 0 && dtype == COUGH_DTYPE_BF16X3 && (Cc == 16 || Cc == 32 || Cc == 64 || Cc == 128) &&
+            (N == 32 || N == 64 || N % 128 == 0)) {
+            // fragment order of cnn_conv_lds_x3_kernel: [k-step][n-tile][hi, lo][64 lanes][8], lo = bf16(w - hi)
+            const int ks = K / 16, nt = N / 32;
+            std::vector<bf16_t> wfr(size_t(ks) * nt * 2 * 512);
+            for (int st = 0; st < ks; ++st)
+                for (int t = 0; t < nt; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const float v = float(wd[size_t(32 * t + (lane & 31)) * K + 16 * st + 8 * (lane >> 5) + jj]);
+                            const bf16_t hi = f2bf_host(v);
+                            const uint32_t hb = uint32_t(hi) << 16;
+                            float hf;
+                            std::memcpy(&hf, &hb, 4);
+                            const size_t base = ((size_t(st) * nt + t) * 2) * 512 + size_t(lane) * 8 + jj;
+                            wfr[base] = hi;
+                            wfr[base + 512] = f2bf_host(v - hf);
+                        }
+            err = cnn_upload(reinterpret_cast<void**>(&l.d_wfrag), wfr);
+        }
         if (!err) err = cnn_upload(reinterpret_cast<void**>(&l.d_b), bf);
         m->layers.push_back(l);
     }
     m->feat_c = w->blocks[w->n_blocks - 1].cout;
     m->hidden = w->hidden;
+    if (!err && dtype == COUGH_DTYPE_BF16X3) {   // the two LDS images of a band can exceed 64 KB
+        const void* fns[] = {
+            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<16, 1, 4, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<16, 1, 4, false>),
+            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<32, 2, 4, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<32, 2, 4, false>),
+            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<64, 4, 2, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<64, 4, 2, false>),
+            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<128, 4, 2, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<128, 4, 2, false>)};
+        for (const void* fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CNN_X3_UNP * 256 * 16 + 64);
+            if (e != hipSuccess && !err) {
+                set_error("cough_cnn_create: %s", hipGetErrorString(e));
+                err = COUGH_EHIP;
+            }
+        }
+    }
     if (!err) {   // fc1 transposed to [C][hidden] for coalesced reads in the head kernel
         std::vector<float> w1t(size_t(m->hidden) * m->feat_c);
         for (int jx = 0; jx < m->hidden; ++jx)

@@ -100,22 +100,6 @@ struct RbxCfg {
     static_assert(LDS * 2 <= 160 * 1024, "two workgroups per CU");
 };
 
-// f32 pair -> packed bf16 pair (round to nearest even, v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {a, b};
-    const bf16x2_t p = __builtin_convertvector(v, bf16x2_t);
-    return __builtin_bit_cast(uint32_t, p);
-}
-// x = hi + lo: hi = bf16(x), lo = bf16(x - hi) for 4 consecutive channels
-__device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
-    hi.x = pk_bf16(a, b);
-    hi.y = pk_bf16(c, d);
-    lo.x = pk_bf16(a - __uint_as_float(hi.x << 16), b - __uint_as_float(hi.x & 0xffff0000u));
-    lo.y = pk_bf16(c - __uint_as_float(hi.y << 16), d - __uint_as_float(hi.y & 0xffff0000u));
-}
-
 template <int CIN, int COUT, int G, int XH, int XW>
 __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     using Cfg = RbxCfg<CIN, COUT, G, XH, XW>;

@@ -326,9 +326,10 @@ class _ConvStackNet(nn.Module):
     subclasses describe their blocks (``_describe``) in terms of their own state_dict keys."""
 
     def _init_native(self, compute_dtype: str):
-        # "fp32" is the parity-grade mode of the conv-stack nets; their single-bf16 mode is approximate and has to be
-        # asked for by that name ('bf16' = deprecated alias, warns); there is no split-bf16 path for them
-        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16_approx"))
+        # "fp32" (exact-f32 MFMA) and "bf16x3" (split-bf16: hi + lo operands, three MFMAs per k-step, f32 activations
+        # in HBM) are the parity-grade modes; the single-bf16 mode is approximate and has to be asked for by that name
+        # ('bf16' = deprecated alias, warns)
+        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16x3", "bf16_approx"))
         self._handle: Optional[C.c_void_p] = None
         self._handle_key = None
         self._tensors = None

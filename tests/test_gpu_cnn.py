@@ -35,6 +35,25 @@ def test_fp32_matches_reference_goldens(cnn_golden, kind):
     assert float((probs.cpu() - vec["probs"]).abs().max()) < 1e-4      # trained-scale head: logits agree to ~1e-4
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_bf16x3_matches_reference_goldens_at_the_logit_tolerance(cnn_golden, kind):
+    """The split-bf16 path of the conv-stack nets (cnn_conv_lds_x3_kernel: hi + lo operands, three MFMAs per k-step, f32
+    activations in HBM) is parity-grade: logits within 1e-3 of the REFERENCE goldens at a trained head's scale, argmax
+    equal on every clip, no margin mask, no relative tolerance."""
+    sd, vec = cnn_golden[kind]
+    m = _model(kind, sd, "bf16x3")
+    x = cnn_golden["x"].cuda()
+    conv = m.conv_output(x).cpu()
+    cerr = float((conv - vec["conv_out"]).abs().max() / vec["conv_out"].abs().max())
+    logits = m(x).cpu()
+    lerr = float((logits - vec["logits"]).abs().max())
+    preds, probs = m.predict(x)
+    print(f"{kind} bf16x3: conv_out {cerr:.2e} (relative to max), logits {lerr:.2e}")
+    assert cerr < 1e-4 and lerr < LOGIT_TOL
+    assert torch.equal(preds.cpu(), vec["preds"])
+    assert float((probs.cpu() - vec["probs"]).abs().max()) < 1e-3
+
+
 # compute_dtype="bf16_approx" of the conv-stack nets is a fast APPROXIMATE mode (single bf16 operands, bf16 activations): on a
 # trained-scale head its logit error is a few percent of the class-margin spread, outside LOGIT_TOL.  The parity-grade
 # mode of these two (SURVEY.md 8f rank 4) classifiers is "fp32" (tests above / below at 1e-4 .. 1e-3).
@@ -64,7 +83,7 @@ def test_bf16_is_an_approximate_mode(cnn_golden, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("dtype,tol", [("fp32", LOGIT_TOL), ("bf16_approx", None)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", LOGIT_TOL), ("bf16x3", LOGIT_TOL), ("bf16_approx", None)])
 def test_fresh_features_ragged_batch_and_other_sizes(cnn_golden, kind, dtype, tol):
     """A batch that is not a multiple of any tile (37 clips), real featuriser output, and a second image size
     (the networks are fully convolutional: global mean at the end)."""
@@ -93,8 +112,8 @@ def test_interface_errors(cnn_golden):
     sd, _ = cnn_golden["small"]
     with pytest.warns(UserWarning, match="APPROXIMATE single-bf16 mode"):      # nobody gets it without being told
         assert cda.create_model("small", compute_dtype="bf16").compute_dtype == "bf16_approx"
-    with pytest.raises(ValueError, match="compute_dtype must be one of 'fp32', 'bf16_approx'"):
-        cda.create_model("standard", compute_dtype="bf16x3")                      # no split-bf16 path for these nets
+    with pytest.raises(ValueError, match="compute_dtype must be one of 'fp32', 'bf16x3', 'bf16_approx'"):
+        cda.create_model("standard", compute_dtype="fp16")
     m = _model("small", sd, "fp32")
     with pytest.raises(ValueError, match="expected input"):
         m(torch.zeros(2, 90, 101))
