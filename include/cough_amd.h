@@ -139,7 +139,7 @@ typedef struct cough_resnet_weights {
                               class-margin spread; outside the 1e-3 parity tolerance for a trained head) */
 #define COUGH_DTYPE_BF16X3 3 /* split-bf16: every operand as hi + lo bf16 (16 significant bits), three MFMAs per k-step
                                 (hi*hi + hi*lo + lo*hi), f32 accumulate, f32 activations in HBM: logits within 1e-3 of
-                                the f32 reference at a trained head's scale.  cough_resnet_create only */
+                                the f32 reference at a trained head's scale.  cough_resnet_create and cough_cnn_create */
 
 typedef struct cough_resnet cough_resnet;
 
