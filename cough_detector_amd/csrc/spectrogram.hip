@@ -5,17 +5,20 @@
 // periodic Hann(400) zero-padded to 512) and, with COUGH_SPEC_FULL_WINDOW | COUGH_SPEC_MAGNITUDE, the magnitude
 // spectrogram T.SpectralCentroid computes internally with its default Hann(n_fft) window (:137-141).
 //
-// The fused featuriser (featurize.hip) never materialises the spectrogram; this kernel is the same FFT with all
-// 257 bins formed and stored.  Algorithmic bytes per clip: 64 000 read + 257*101*4 = 103 828 written.
+// The fused featuriser (featurize.hip) never materialises the spectrogram; this file is the same FFT with all 257 bins
+// formed and stored.  Algorithmic bytes per clip: 64 000 read + 257*101*4 = 103 828 written.
 //
-// One 4-wave workgroup per (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames), three resident per
-// CU.  A wave transforms 4 frames at a time (16 lanes each): lane j of a frame ends up with Z[j+16*k2]; with its
-// partner's Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and X[256-k] -- conj(E - W^k O) -- so every bin 0..256
-// comes out of the same 8 butterflies.  The (bin, time) output is time-minor, so the chunk's powers are staged in
-// LDS and flushed as ~100-byte row fragments.  The four chunks of a clip sit on workgroup ids 8 apart: same XCD
-// (ids are dealt round-robin over the 8 XCDs), dispatched together, so the fragments of one 404-byte row meet in
-// that XCD's L2 and leave as whole lines: WRITE_SIZE = 1.004x the algorithmic bytes (1.34x with one workgroup
-// per clip flushing chunk after chunk; 1.29x with a persistent grid, whose sibling workgroups drift apart).
+// The kernel that runs is stft3_kernel (below): one persistent 13-wave workgroup per CU owns a clip's whole spectrogram,
+// stages it in LDS as the linear image it is in memory and writes it with aligned 16-byte stores; samples arrive by
+// LDS-DMA.  0.169 ms for 4096 clips = 51 % of 8 TB/s, PMC traffic 1.001x (profiles/r03_stft_experiments.txt).
+//
+// stft_kernel (first below) is the round-1/2 design, kept behind COUGH_STFT_V1 for same-box A/B only: one 4-wave
+// workgroup per (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames), three resident per CU.  A wave
+// transforms 4 frames at a time (16 lanes each): lane j of a frame ends up with Z[j+16*k2]; with its partner's
+// Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and X[256-k] -- conj(E - W^k O) -- so every bin 0..256 comes out of
+// the same 8 butterflies.  The (bin, time) output is time-minor, so the chunk's powers are staged in LDS and flushed
+// as ~100-byte row fragments; the four chunks of a clip sit on workgroup ids 8 apart (same XCD, dispatched together)
+// so that the fragments of one 404-byte row meet in that XCD's L2 (WRITE_SIZE 1.004x; 0.2445 ms = 35 %).
 #include <cstdlib>
 
 #include "common.h"

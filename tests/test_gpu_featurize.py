@@ -229,6 +229,31 @@ def test_stft_stage_full_batch_parseval(pre):
     assert torch.equal(p[:64], p[-64:])                                  # deterministic across workgroups
 
 
+@pytest.mark.parametrize("b", [1, 255, 300, 513])
+def test_stft_stage_persistent_grid_and_output_alignment(pre, b):
+    """The STFT kernel is persistent (one workgroup per CU striding over the clips) and writes a clip's image with
+    16-byte stores whose alignment follows the OUTPUT address: batches below / around / above the CU count (workgroups
+    with 0, 1 and 2 clips), strided waveform rows, and an output pointer at every 4-byte phase -- each must give
+    bit-identical spectrograms for the same clip, equal to the oracle's."""
+    from cough_detector_amd import _lib
+    pool = synth_batch(500, 16)
+    ref = ofeat.stft_power(pool, win=400, power=2.0)
+    idx = torch.arange(b) % 16
+    wav = torch.zeros((b, 16004), device="cuda")
+    wav[:, :16000] = pool[idx].cuda()
+    base = pre.spectrogram_batch(wav[:, :16000]).cpu()                    # row stride 16004
+    assert _spec_err(base[:16], ref[idx[:16]], 1e-5) < FEAT_TOL
+    assert torch.equal(base, base[:16][idx] if b >= 16 else base)          # every copy of a clip: the same bits
+    lib, img = _lib.load(), 257 * 101
+    for phase in (1, 2, 3):
+        buf = torch.full((b * img + 8,), float("nan"), device="cuda")
+        out = buf[phase:phase + b * img]
+        _lib.check(lib.cough_spectrogram(pre._native(), wav.data_ptr(), 16004, out.data_ptr(), b, 0,
+                                         torch.cuda.current_stream().cuda_stream), "cough_spectrogram")
+        assert torch.equal(out.view(b, 257, 101).cpu(), base), phase
+        assert bool(torch.isnan(buf[:phase]).all()) and bool(torch.isnan(buf[phase + b * img:]).all())   # nothing outside
+
+
 @pytest.mark.parametrize("n_bands", [1, 2, 3, 4])
 def test_spectral_contrast_rows_against_oracle(n_bands):
     """use_spectral_contrast=True (preprocessing.py:242-303, :476-480): band contrast + centroid rows, z-scored
