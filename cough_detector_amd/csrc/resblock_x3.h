@@ -118,6 +118,12 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
 #ifndef RBX_PRIO
 #define RBX_PRIO 0
 #endif
+#ifndef RBX_TAIL_SWAP
+#define RBX_TAIL_SWAP 0   // 1 (experiment, correct, SLOWER): the 16-row tile's 16x16x32 weight fragments are re-arranged from the
+                          // 32x32x16 fragments the wave already holds (v_permlane32_swap + v_permlane16_swap) instead of being
+                          // streamed a second time from L2 -- removes 29 % of the kernel's L1 accesses and costs +2-3 % of the
+                          // classifier time (profiles/r03_resblock_experiments.txt): the k-loop is issue-bound, not L1-bound
+#endif
     constexpr int D = RBX_D;   // weight prefetch depth (k-steps; one k-step = MW x 3 MFMAs >= 192 cycles)
     extern __shared__ __attribute__((aligned(256))) char smem[];
     float* lbias = reinterpret_cast<float*>(smem + Cfg::BIAS);
@@ -143,15 +149,18 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     for (int i = 0; i < D; ++i) { ring[i][0] = wfrag(i, 0); ring[i][1] = wfrag(i, 1); }
     // TAIL: this wave's 16 channels (tile `wave`) of the 16-row tile, in k32-steps
     constexpr int DT = D / 2 > 0 ? D / 2 : 1;
-    const bf16_t* wtbase = TAIL ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
+    const bf16_t* wtbase = (TAIL && !RBX_TAIL_SWAP) ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
     auto wtfrag = [&](int q, int plane) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(wtbase + (size_t(q) * Cfg::WAVES * 2 + plane) * 512);
     };
     bf16x8 tring[DT][2];
-    if constexpr (TAIL) {
+    if constexpr (TAIL && !RBX_TAIL_SWAP) {
 #pragma unroll
         for (int i = 0; i < DT; ++i) { tring[i][0] = wtfrag(i, 0); tring[i][1] = wtfrag(i, 1); }
     }
+    // TAIL: the 16 output channels this wave owns in the 16-row tile.  With RBX_TAIL_SWAP they are the half `mg` of the
+    // wave's own 32-channel tile `ng` (so that its weights are the ones already in its ring); otherwise tile `wave`.
+    const int tch = RBX_TAIL_SWAP ? 32 * ng + 16 * mg : 16 * wave;
 
     // ---- stage: the clips' x (f32) is one linear run of 16-byte pieces = 4 channels of one pixel; all loads are
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         for (int mt = 0; mt < MWX; ++mt) { acc1[mt] = f32x16{0}; acc2[mt] = f32x16{0}; }
         f32x4 tacc1 = {0.f, 0.f, 0.f, 0.f}, tacc2 = {0.f, 0.f, 0.f, 0.f};
         bf16x8 taf[2];
+        bf16x8 tw_prev[2] = {};   // RBX_TAIL_SWAP: the (hi, lo) weight fragments of the even k-step, kept for the odd one
         int ttadr = 0;
         // TAIL fragments of k32-step q (q counts 32-wide steps through conv1, projection, conv2)
         auto tfrag = [&](auto qc) {
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                     }
                 }
                 if constexpr (TAIL) {
-                    const int n0 = 16 * wave + 4 * tq;
+                    const int n0 = tch + 4 * tq;
                     const float4 bb = *reinterpret_cast<const float4*>(lbias + n0);
                     uint2 hi, lo;
                     split4(fmaxf(tacc1[0] + bb.x, 0.f), fmaxf(tacc1[1] + bb.y, 0.f), fmaxf(tacc1[2] + bb.z, 0.f),
@@ -369,6 +379,18 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             // free.  Left alone, the scheduler sinks every ds_read next to its MFMA and each pays the LDS latency; one
             // filler group per MFMA triple (the first version) left the pipe idle behind every third MFMA (+2.3 %).
             const bf16x8 whi = ring[s % D][0], wlo = ring[s % D][1];
+            bf16x8 tsw_hi = {}, tsw_lo = {};
+            if constexpr (TAIL && RBX_TAIL_SWAP) {
+                if constexpr (s % 2 == 0) {
+                    tw_prev[0] = whi;
+                    tw_prev[1] = wlo;
+                } else {
+                    // re-arranged here, at the head of the odd step, so that the 16 lane swaps issue in the shadow of the
+                    // 32-row tiles' MFMAs instead of in front of the 16-row tile's
+                    tsw_hi = tail_swap(tw_prev[0], whi, mg);
+                    tsw_lo = tail_swap(tw_prev[1], wlo, mg);
+                }
+            }
 #pragma unroll
             for (int mt = 0; mt < MWX; ++mt) {
                 constexpr bool pf = s + 1 < KS && s + 1 != KS1 + KSP;
@@ -399,8 +421,20 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 if constexpr (s % 2 == 0) {
                     tfrag(std::integral_constant<int, q>{});
                 } else {
-                    const bf16x8 twhi = tring[q % DT][0], twlo = tring[q % DT][1];
-                    if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
+                    bf16x8 twhi, twlo;
+                    if constexpr (RBX_TAIL_SWAP) {
+                        // A = fragment of k-step 2q (tw_prev), B = that of 2q + 1 (this step's): lane (r, h) holds
+                        // W[32 ng + r][16 s + 8 h ..].  As 16-lane rows A = (A0 A1 A2 A3): A0 / A1 = channels 0-15 / 16-31 at
+                        // h = 0, A2 / A3 at h = 1.  A 16x16x32 fragment wants lane (i, c) = W[16 t + i][32 q + 8 c ..]:
+                        // rows (A0 A2 B0 B2) for the lower 16 channels, (A1 A3 B1 B3) for the upper.  permlane32_swap(A, B)
+                        // gives (A0 A1 B0 B1), (A2 A3 B2 B3); permlane16_swap of those two gives exactly the two wanted.
+                        twhi = tsw_hi;
+                        twlo = tsw_lo;
+                    } else {
+                        twhi = tring[q % DT][0];
+                        twlo = tring[q % DT][1];
+                        if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
+                    }
 #if RBX_PIN
                     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             }
         }
         if constexpr (TAIL) {
-            const int n0 = 16 * wave + 4 * tq;
+            const int n0 = tch + 4 * tq;
             const float4 bb = *reinterpret_cast<const float4*>(lbias + COUT + n0);
             const float4 o = make_float4(fmaxf(tacc2[0] + bb.x, 0.f), fmaxf(tacc2[1] + bb.y, 0.f),
                                          fmaxf(tacc2[2] + bb.z, 0.f), fmaxf(tacc2[3] + bb.w, 0.f));
