@@ -33,7 +33,6 @@
 #include "nn_common.h"
 #include "conv_gemm.h"
 #include "resblock_x3.h"
-#include "resblock_x3p.h"
 
 #define COUGH_DTYPE_DIRECT 2
 
@@ -1095,24 +1094,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                 ra.b1 = m->d_b[k.s1];
                 ra.b2 = m->d_b[k.s2];
                 ra.out = reinterpret_cast<float*>(k.out);
-                if (i == 0 && getenv("COUGH_RBXP")) {
-                    // EXPERIMENT (resblock_x3p.h): persistent 9-wave block 0 fed by LDS-DMA from a pre-split plane image
-                    using PCfg = RbxpCfg<32, 64, 22, 25>;
-                    static unsigned char* d_planes = nullptr;
-                    static size_t planes_cap = 0;
-                    const size_t need = size_t(n) * PCfg::BUF;
-                    if (need > planes_cap) {
-                        if (d_planes) (void)hipFree(d_planes);
-                        COUGH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_planes), need));
-                        planes_cap = need;
-                        COUGH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_x3p_kernel<32, 64, 22, 25>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::LDS));
-                    }
-                    hipLaunchKernelGGL((rbxp_planes_kernel<32, 64, 22, 25>), dim3(n), dim3(256), 0, st, ra.x, d_planes, n);
-                    int cus = 256;
-                    hipLaunchKernelGGL((resblock_x3p_kernel<32, 64, 22, 25>), dim3(n < cus ? n : cus), dim3(PCfg::THREADS), PCfg::LDS,
-                                       st, ra, d_planes);
-                } else if (i == 0) {
+                if (i == 0) {
                     using Cfg = RbxCfg<32, 64, 1, 22, 25>;
                     hipLaunchKernelGGL((resblock_x3_kernel<32, 64, 1, 22, 25>), dim3(n), dim3(Cfg::THREADS), Cfg::LDS, st, ra);
                 } else {
