@@ -1,0 +1,53 @@
+"""The driver's contract with bench.py, checked in-process on the GPU (no child process): ONE JSON line with the fields
+the prompt's measurement section names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the dominant kernel and a
+`cpu_baseline` object -- at a small batch so that it runs in seconds."""
+import json
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, capsys, *argv):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("COUGH_BENCH_FORCE_DIST", raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_line_has_every_contract_field(monkeypatch, capsys):
+    d = _run(monkeypatch, capsys, "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "512", "--cpu-seconds", "1.0",
+             "--prewarm-s", "0.05")
+    assert d["metric"].startswith("1s@16kHz clips/sec") and d["unit"] == "clips/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"].startswith("bf16x3") and "workload" in d["config"]
+    assert "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert r["algorithmic_bytes_per_launch"] == 512 * 100360                   # 64 000 read + 36 360 written
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["ms_per_launch"] < d["ms_per_step"]                               # the dominant kernel fits inside the step
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c
+    assert c["kind"] == "port" and c["unit"] == "clips/s" and c["value"] > 0 and c["cores"] >= 1
+    cl = d["roofline_classifier"]
+    assert cl["bound"] == "mfma" and cl["peak"] == 2500.0 and 0 < cl["frac"] < 1 and cl["mfma_per_product"] == 3
+    s = d["roofline_stft"]
+    assert s["bound"] == "hbm" and s["algorithmic_bytes_per_launch"] == 512 * 167828 and 0 < s["frac"] < 1
+
+
+def test_short_total_clips_stream_does_not_crash(monkeypatch, capsys):
+    """a --total-clips stream shorter than one batch has no full step; the line must still come out."""
+    d = _run(monkeypatch, capsys, "--total-clips", "300", "--batch", "512", "--cpu-seconds", "0", "--prewarm-s", "0.05")
+    assert d["scaling"] == "strong" and d["steps"] == 1 and d["value"] > 0
+    assert d["roofline"]["clips_per_launch"] == 300 and "roofline_stft" not in d
