@@ -226,6 +226,10 @@ def main():
     args.gpus = world
     from cough_detector_amd.hostcpu import bound_torch_threads
     bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
+    share_gpu = os.environ.get("COUGH_BENCH_SHARE_GPU") == "1"       # REHEARSAL only: several ranks on one card
+    backend = os.environ.get("COUGH_BENCH_BACKEND", "nccl")          # REHEARSAL only: "gloo" (RCCL refuses two ranks per GPU)
+    if share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if torch.cuda.device_count() <= local_rank:       # a rank may touch the runtime; the launching parent may not
         print(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible on this node "
               f"(rank {rank} needs device {local_rank})", file=sys.stderr)
@@ -241,7 +245,10 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         dist.barrier()        # builds the communicator now (tens of ms): the barriers around the timed region are then
                               # short, and the GPU does not idle its clocks down just before the first timed step
 
@@ -357,7 +364,7 @@ def main():
             workload = "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32"
         elif args.total_clips > 0:
             workload = (f"configs[3]: {args.total_clips}-clip synthetic stream, every clip distinct, generated on-device "
-                        "from its index, resident in HBM, sharded round-robin, one pass in batches of 4096 per rank -> "
+                        f"from its index, resident in HBM, sharded round-robin, one pass in batches of {B} per rank -> "
                         "90x101 features -> CoughDetectorResidual logits, all-gather of logits")
         else:
             workload = ("configs[2]: batch=4096 synthetic 1s@16kHz mono per GPU -> 90x101 features "
@@ -370,7 +377,10 @@ def main():
             "scaling": "strong" if args.total_clips > 0 else "weak", "vs_baseline": None,
             "dtype": "f32" if args.featurize_only else DTYPE_LABEL[args.dtype], "data": "synthetic",
             "prewarm_s": round(prewarm_s, 3),
-            "config": {"workload": workload, "clips_per_gpu_per_step": B, "sharding": f"round-robin over {world} rank(s)",
+            "config": {"workload": workload, "clips_per_gpu_per_step": B,
+                       "sharding": f"round-robin over {world} rank(s)" +
+                                   (f" -- REHEARSAL: backend {backend}, ranks share one GPU: not a scaling measurement"
+                                    if (share_gpu or backend != "nccl") else ""),
                        "collective": (f"all_gather(logits) once per {args.gather_every} steps ({args.gather_every * B * 8} B per rank), "
                                       "overlapped with the next bucket's compute") if dist else "none",
                        "inputs": (f"{len(batches)} distinct device-resident batches" if args.total_clips > 0 else

@@ -3,7 +3,11 @@ the flush across the end of the stream have only ever run with one rank or on gl
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/rccl_multirank_check.py
 
-(start it with torchrun: the launcher never touches the GPU).  Every rank scores its round-robin shard of a ragged
+(start it with torchrun: the launcher never touches the GPU).  On a ONE-GPU box the same job can be rehearsed with W ranks
+sharing the card -- RCCL refuses two ranks on one device, so the exchange then runs on gloo (CUDA tensors staged through
+the host): `COUGH_CHECK_BACKEND=gloo COUGH_CHECK_SHARE_GPU=1 python -m torch.distributed.run ... --nproc-per-node 2 ...`
+exercises the W = 2 shard -> generate -> score -> bucketed gather -> un-interleave path with the real kernels; only the
+transport differs.  Every rank scores its round-robin shard of a ragged
 synthetic stream through CoughPipeline + BucketedLogitsGather on RCCL (`distributed.score_stream`), then scores the
 WHOLE stream alone; the gathered logits must be bit-identical to the single-rank ones on every rank.  Not part of
 `pytest -m gpu`: the one-GPU boxes cannot run it, and a test process that has initialised the GPU may not start ranks."""
@@ -21,9 +25,15 @@ from cough_detector_amd import distributed as cdist, synth
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("COUGH_CHECK_BACKEND", "nccl")
+    if os.environ.get("COUGH_CHECK_SHARE_GPU") == "1":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     pre = cda.AudioPreprocessor(device="cuda", use_pcen=False, use_pre_emphasis=False, use_delta_delta=False,
                                 use_spectral_contrast=False)
     model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
@@ -42,7 +52,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     if rank == 0:
-        print("RCCL multi-rank exchange:", "OK" if t.item() == 1.0 else "MISMATCH")
+        print(f"{backend} multi-rank exchange ({world} ranks):", "OK" if t.item() == 1.0 else "MISMATCH")
     sys.exit(0 if t.item() == 1.0 else 1)
 
 
