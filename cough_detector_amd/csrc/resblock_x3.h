@@ -93,10 +93,13 @@ struct RbxCfg {
     static constexpr int HRED = BIAS + 2 * COUT * 4;                         // head reduction scratch [WAVES][2] f32
     static constexpr int LDS = HRED + WAVES * 2 * 4;
     static constexpr int OP = COUT + 4;                                      // floats per row of the f32 output tile
+    // pre-split image of ONE clip of this block's INPUT in HBM (RBX_A2_PRESPLIT): [hi, lo][CHI chunk planes][NPP cells] x 16 B
+    static constexpr int IMG1 = 2 * XH * OW;                                 // cells of one clip in one chunk plane (= NPP / G)
+    static constexpr int IMGB = 2 * CHI * IMG1 * 16;                         // bytes per clip
     static_assert(WAVES % NT == 0 && MG * MW * 32 + (TAIL ? 16 : 0) >= M, "tile split");
     static_assert(OW == (XW + 1) / 2, "sub-image row pitch");
     static_assert(M * OP * 4 <= 2 * PL, "the output tile lies over the planes");
-    static_assert((G * NPX * CIN / 4 + THREADS - 1) / THREADS <= 18, "staging registers");
+    static_assert((G * NPX * CIN / 4 + THREADS - 1) / THREADS <= 18, "staging registers (f32 input)");
     static_assert(LDS * 2 <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -117,6 +120,14 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
 #endif
 #ifndef RBX_PRIO
 #define RBX_PRIO 0
+#endif
+#ifndef RBX_A2_PRESPLIT
+#define RBX_A2_PRESPLIT 0   // 1 (experiment, correct, NO GAIN): block 0 stores its output already split (hi, lo bf16 pairs: the
+                            // same 4 bytes per value, the same rounding point, so block 1's operands and the logits are
+                            // bit-identical) and in block 1's LDS plane order; block 1 then stages its input with plain 16-byte
+                            // copies -- no split, one ds_write_b128 per piece.  cls 0.3854 -> 0.3886 ms
+                            // (profiles/r03_resblock_experiments.txt (h)): the staging phase is bound by arrival, not by its
+                            // instructions
 #endif
 #ifndef RBX_TAIL_SWAP
 #define RBX_TAIL_SWAP 0   // 1 (experiment, correct, SLOWER): the 16-row tile's 16x16x32 weight fragments are re-arranged from the
@@ -162,6 +173,30 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     // wave's own 32-channel tile `ng` (so that its weights are the ones already in its ring); otherwise tile `wave`.
     const int tch = RBX_TAIL_SWAP ? 32 * ng + 16 * mg : 16 * wave;
 
+    if constexpr (RBX_A2_PRESPLIT && CIN == 64) {
+        // ---- stage (pre-split input, written by block 0 in this kernel's plane order): per clip a linear run of 16-byte
+        // cells [hi, lo][chunk][cell]; each goes to cell (g * NPP + cell) of its chunk plane as it is ----
+        constexpr int IMG1 = Cfg::IMG1, PERCLIP = 2 * CHI * IMG1, NPIECE = G * PERCLIP, UN = (NPIECE + THREADS - 1) / THREADS;
+        static_assert(UN <= 20, "staging registers");
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.x) + (long long)clip0 * Cfg::IMGB);
+        const int valid = nvalid * PERCLIP;
+        uint4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = tid + u * THREADS;
+            v[u] = src[i < valid ? i : valid - 1];
+        }
+        if (tid < 2 * CHI) *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = tid + u * THREADS;
+            if (i < NPIECE) {
+                const int g = i / PERCLIP, rem = i % PERCLIP, pl = rem / (CHI * IMG1), q = (rem % (CHI * IMG1)) / IMG1, c = rem % IMG1;
+                if (i >= valid) v[u] = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(smem + pl * PL + q * CPX + (g * NPP + c) * 16) = v[u];
+            }
+        }
+    } else {
     // ---- stage: the clips' x (f32) is one linear run of 16-byte pieces = 4 channels of one pixel; all loads are
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
     {
@@ -195,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 *reinterpret_cast<uint2*>(smem + off + PL) = lo;
             }
         }
+    }
     }
     if (tid < COUT) { lbias[tid] = bv1; lbias[COUT + tid] = bv2; }
     float fw0 = 0.f, fw1 = 0.f, fb0 = 0.f, fb1 = 0.f;   // fused head (block 1): Linear(128, 2) weights of channel tid & 127
@@ -496,7 +532,27 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     __syncthreads();
     RB_STAMP(6);
     const float* otile = reinterpret_cast<const float*>(smem);
-    if (a.out != nullptr) {
+    if constexpr (RBX_A2_PRESPLIT && COUT == 64) {
+        // the next block's input image: (pixel, 8-channel chunk) -> one hi cell and one lo cell, at the pixel's place in
+        // the parity-split order of the NEXT block (row pitch of its output image)
+        static_assert(G == 1, "one clip per workgroup");
+        constexpr int OW2 = (OW + 1) / 2, RE2 = (OH + 1) / 2, RO2 = OH / 2;             // next block: OW, even / odd rows
+        constexpr int B01 = RE2 * OW2, B10 = 2 * RE2 * OW2, B11 = 2 * RE2 * OW2 + RO2 * OW2, IMG2 = 2 * OH * OW2;
+        if (a.out != nullptr && nvalid > 0) {
+            char* o = reinterpret_cast<char*>(a.out) + (long long)clip0 * (2 * CHO * IMG2 * 16);
+            for (int p = tid; p < PER * CHO; p += THREADS) {
+                const int row = p / CHO, q = p % CHO, oh = row / OW, ow = row % OW;
+                const int cell = ((oh & 1) ? ((ow & 1) ? B11 : B10) : ((ow & 1) ? B01 : 0)) + (oh >> 1) * OW2 + (ow >> 1);
+                const float4 v0 = *reinterpret_cast<const float4*>(otile + row * OP + 8 * q);
+                const float4 v1 = *reinterpret_cast<const float4*>(otile + row * OP + 8 * q + 4);
+                uint2 h0, l0, h1, l1;
+                split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
+                split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
+                *reinterpret_cast<uint4*>(o + (q * IMG2 + cell) * 16) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *reinterpret_cast<uint4*>(o + ((CHO + q) * IMG2 + cell) * 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        }
+    } else if (a.out != nullptr) {
         const int nvec = nvalid * PER * (COUT / 4);
         float4* o = reinterpret_cast<float4*>(a.out + (long long)clip0 * PER * COUT);
         for (int p = tid; p < nvec; p += THREADS) {

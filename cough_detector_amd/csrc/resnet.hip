@@ -929,11 +929,29 @@ Workspace carve(const cough_resnet* m, char* base, int n, const Shapes& s) {
     auto take = [&](size_t elems) { char* p = base + off; off += align256(elems * m->esize); return p; };
     w.a1 = take(size_t(n) * s.P1h * s.P1w * 32);
     w.h0 = take(size_t(n) * s.B0h * s.B0w * 64);
-    w.a2 = take(size_t(n) * s.B0h * s.B0w * 64);
+    // bf16x3, shipped image: block 0 hands a2 over pre-split in block 1's LDS plane order (RBX_A2_PRESPLIT): hi + lo
+    // cells incl. the parity-split pad cells, 39 424 B per clip instead of 36 608
+    size_t a2_elems = size_t(n) * s.B0h * s.B0w * 64;
+    if (RBX_A2_PRESPLIT && m->dtype == COUGH_DTYPE_BF16X3 && s.P1h == 22 && s.P1w == 25)
+        a2_elems = std::max(a2_elems, size_t(n) * (RbxCfg<64, 128, 2, 11, 13>::IMGB / 4));
+    w.a2 = take(a2_elems);
     w.h1 = take(size_t(n) * s.B1h * s.B1w * 128);
     w.a3 = take(size_t(n) * s.B1h * s.B1w * 128);
     w.total = off;
     return w;
+}
+
+// parity tap of the pre-split a2 image (block 1's plane order, RbxCfg<64, 128, 2, 11, 13>) -> NCHW f32, value = hi + lo
+__global__ void presplit_to_nchw_kernel(const unsigned char* __restrict__ planes, float* __restrict__ out, long long total) {
+    using Cfg = RbxCfg<64, 128, 2, 11, 13>;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const int w = int(i % 13), h = int((i / 13) % 11), c = int((i / 143) % 64);
+    const long long n = i / (143 * 64);
+    const int cell = ((h & 1) ? ((w & 1) ? Cfg::PB11 : Cfg::PB10) : ((w & 1) ? Cfg::PB01 : 0)) + (h >> 1) * Cfg::OW + (w >> 1);
+    const bf16_t* img = reinterpret_cast<const bf16_t*>(planes + n * Cfg::IMGB);
+    const int e = ((c >> 3) * Cfg::IMG1 + cell) * 8 + (c & 7);
+    out[i] = bf2f(img[e]) + bf2f(img[Cfg::CHI * Cfg::IMG1 * 8 + e]);
 }
 
 // ------------------------------------------------------------------------------ generic channel tuples (f32)
@@ -1410,6 +1428,15 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
     COUGH_REQUIRE(which >= 1 && which <= 3, COUGH_EINVAL, "cough_resnet_read_activation: which must be 1..3");
     const Shapes s = make_shapes(height, width);
     const Workspace w = carve(m, const_cast<char*>(static_cast<const char*>(d_workspace)), n_clips, s);
+    if (which == 2 && RBX_A2_PRESPLIT && m->dtype == COUGH_DTYPE_BF16X3 && s.P1h == 22 && s.P1w == 25) {
+        // a2 lives as block 1's pre-split plane image: value = hi + lo (16 significant bits of the f32 activation)
+        const long long total = (long long)n_clips * 64 * 11 * 13;
+        if (total == 0) return COUGH_OK;
+        hipLaunchKernelGGL(presplit_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned char*>(w.a2), d_out, total);
+        COUGH_HIP_CHECK(hipGetLastError());
+        return COUGH_OK;
+    }
     const char* src = which == 1 ? w.a1 : which == 2 ? w.a2 : w.a3;
     const int C = which == 1 ? 32 : which == 2 ? 64 : 128;
     const int HW = which == 1 ? s.P1h * s.P1w : which == 2 ? s.B0h * s.B0w : s.B1h * s.B1w;
