@@ -168,15 +168,21 @@ def build_launch_cmd(argv, n_ranks: int, port: int):
 
 
 def launch_ranks(args, argv) -> int:
-    """Parent of a multi-rank run.  It stays subprocess-only and never touches the GPU runtime: devices are counted
-    from the KFD topology in sysfs (``hostcpu.visible_gpu_count``), not with ``torch.cuda.device_count()``, which may
-    initialise HIP.  When the topology cannot be read the check is skipped and the ranks report a shortage."""
-    from cough_detector_amd.hostcpu import visible_gpu_count
+    """Parent of a multi-rank run.  It stays subprocess-only and never touches the GPU runtime.  It refuses to start only
+    on EXPLICIT evidence of a shortage -- a ``*_VISIBLE_DEVICES`` variable that names fewer devices than ``--gpus``
+    (``hostcpu.explicit_device_limit``).  The sysfs count (``hostcpu.visible_gpu_count``: KFD topology + render-node
+    access) is a heuristic that may under-count in an unfamiliar container, so a shortage there is only a warning: the
+    ranks' own ``torch.cuda.device_count()`` decides, and a rank without a device says so and exits 2."""
+    from cough_detector_amd.hostcpu import explicit_device_limit, visible_gpu_count
+    limit = explicit_device_limit()
+    if limit is not None and limit < args.gpus:
+        print(f"bench.py --gpus {args.gpus}: only {limit} device(s) visible on this node "
+              f"(ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES names {limit})", file=sys.stderr)
+        return 2
     have = visible_gpu_count()
     if have is not None and have < args.gpus:
-        print(f"bench.py --gpus {args.gpus}: only {have} device(s) visible on this node "
-              f"(ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES?)", file=sys.stderr)
-        return 2
+        print(f"bench.py --gpus {args.gpus}: WARNING: sysfs shows only {have} device(s) (KFD topology / render nodes); "
+              f"launching anyway -- each rank checks its own device", file=sys.stderr)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -211,7 +217,13 @@ def parse_args(argv=None):
     ap.add_argument("--total-clips", type=int, default=0,
                     help="configs[3]: one pass over a stream of this many distinct clips (all ranks together); "
                          "overrides --steps and --rotate")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.dtype == "bf16":              # the pre-r03 name of the approximate mode (argparse does not check an env default)
+        print("bench.py: COUGH_BENCH_DTYPE=bf16 is the APPROXIMATE single-bf16 mode, now called bf16_approx", file=sys.stderr)
+        args.dtype = "bf16_approx"
+    if args.dtype not in DTYPE_LABEL:
+        ap.error(f"unknown dtype {args.dtype!r} (COUGH_BENCH_DTYPE / --dtype): choose from {sorted(DTYPE_LABEL)}")
+    return args
 
 
 def main():
@@ -224,12 +236,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    from cough_detector_amd.hostcpu import bound_torch_threads
-    bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
+    from cough_detector_amd.hostcpu import bind_to_gpu_numa, bound_torch_threads
     share_gpu = os.environ.get("COUGH_BENCH_SHARE_GPU") == "1"       # REHEARSAL only: several ranks on one card
     backend = os.environ.get("COUGH_BENCH_BACKEND", "nccl")          # REHEARSAL only: "gloo" (RCCL refuses two ranks per GPU)
     if share_gpu:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    # multi-rank: pin this rank's host threads to the NUMA node of ITS GPU (sysfs only, before any GPU call and before
+    # the thread pools exist); single process: leave the affinity alone
+    numa = bind_to_gpu_numa(local_rank) if (world > 1 and os.environ.get("COUGH_BENCH_NUMA", "1") == "1") else \
+        {"numa_node": None, "pci": None, "cpus": None}
+    bound_torch_threads()          # size host thread pools to the cgroup CPU share (else the process is throttled)
     if torch.cuda.device_count() <= local_rank:       # a rank may touch the runtime; the launching parent may not
         print(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible on this node "
               f"(rank {rank} needs device {local_rank})", file=sys.stderr)
@@ -338,6 +354,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,6 +366,18 @@ def main():
     k1_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in full) / max(len(full), 1)
     net_ms = 0.0 if args.featurize_only else sum(ev[i][1].elapsed_time(ev[i][2]) for i in full) / max(len(full), 1)
 
+    rank_records = None
+    if dist:
+        # what proves the collective path ran: every rank's own device / clock / kernel times / exchange counters,
+        # gathered with ONE small all-gather after the timed region
+        from cough_detector_amd.distributed import gather_rank_records
+        rank_records = gather_rank_records({
+            "rank": rank, "device": local_rank, "numa_node": -1 if numa["numa_node"] is None else numa["numa_node"],
+            "host_cpus": -1 if numa["cpus"] is None else numa["cpus"],
+            "ms_per_step": elapsed_local / max(K, 1) * 1e3, "k1_ms": k1_ms, "cls_ms": net_ms,
+            "clips": sum(int(b_.shape[0]) for b_ in batches[:K]),
+            "collectives_started": publisher.collectives if publisher else 0,
+            "collectives_finished": publisher.finished if publisher else 0}, dev)
     if rank == 0:
         total_clips = sum(step_total)
         # the featurise stage's algorithmic bytes are 64 000 read + 36 360 written per clip, fused or not.
@@ -415,6 +444,15 @@ def main():
         if world == 1 and not dist and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if dist:
+            line["rccl_world"] = dist.get_world_size()
+            line["backend"] = ("rccl (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl"
+                               else dist.get_backend())
+            line["ranks"] = rank_records
+            line["collectives"] = {"started": min(r["collectives_started"] for r in rank_records),
+                                   "finished": min(r["collectives_finished"] for r in rank_records),
+                                   "per": f"{args.gather_every} steps", "skipped": skip_gather}
+            line["numa_binding"] = ({"pci": numa["pci"], "numa_node": numa["numa_node"], "cpus": numa["cpus"]}
+                                    if world > 1 else None)
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

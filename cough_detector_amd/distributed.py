@@ -206,3 +206,28 @@ def score_stream(pipeline, total_clips: int, batch: int = 4096, every: int = 8, 
     if done != total_clips:
         raise RuntimeError(f"stream exchange incomplete: {done} of {total_clips} clips gathered")
     return full
+
+
+def gather_rank_records(record: dict, device, group=None) -> list:
+    """One small all-gather of a flat numeric record per rank (same keys on every rank); returns the list of the
+    ranks' records in rank order, on every rank.  ``bench.py`` uses it after the timed region to put every rank's own
+    device / clock / kernel times / exchange counters on the N > 1 line."""
+    keys = sorted(record)
+    mine = torch.tensor([float(record[k]) for k in keys], dtype=torch.float64, device=device)
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        rows = torch.stack(parts).cpu()
+    else:
+        rows = torch.empty((world, len(keys)), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(rows, mine, group=group)
+        rows = rows.cpu()
+    out = []
+    for r in range(world):
+        rec = {}
+        for j, k in enumerate(keys):
+            v = float(rows[r, j])
+            rec[k] = int(v) if v == int(v) and not k.endswith("_ms") and k != "ms_per_step" else round(v, 4)
+        out.append(rec)
+    return out

@@ -63,3 +63,90 @@ def visible_gpu_count(kfd_root: str = "/sys/class/kfd/kfd/topology/nodes", envir
         if val is not None:
             n = min(n, len([v for v in val.split(",") if v.strip() != ""]))
     return n
+
+
+def explicit_device_limit(environ=None):
+    """The device count a ``*_VISIBLE_DEVICES`` variable EXPLICITLY grants (the smallest, when several are set), or
+    ``None`` when none is set.  This is the only evidence on which a multi-rank launcher may refuse to start: the sysfs
+    heuristics of ``visible_gpu_count`` can under-count in an unfamiliar container, an operator's own variable cannot."""
+    environ = os.environ if environ is None else environ
+    limit = None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = environ.get(var)
+        if val is not None:
+            n = len([v for v in val.split(",") if v.strip() != ""])
+            limit = n if limit is None else min(limit, n)
+    return limit
+
+
+def _parse_cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(local_rank: int, kfd_root: str = "/sys/class/kfd/kfd/topology/nodes", drm_root: str = "/sys/class/drm",
+                  environ=None, dri_root: str = "/dev/dri"):
+    """``(numa_node, pci_address)`` of the GPU that HIP device ``local_rank`` will be, read from sysfs WITHOUT touching
+    the runtime: the KFD topology lists GPU nodes in the runtime's enumeration order, each with the minor number of its
+    DRM render node, and ``/sys/class/drm/renderD<minor>/device`` is the PCI function, whose ``numa_node`` names the host
+    memory node it hangs off.  Nodes whose render node this process may not open are skipped (a container is handed only
+    its own), and an index list in ``ROCR_VISIBLE_DEVICES`` / ``HIP_VISIBLE_DEVICES`` is applied.  ``(None, None)``
+    whenever any step cannot be read -- the caller then leaves the affinity alone."""
+    environ = os.environ if environ is None else environ
+    try:
+        gpus = []
+        for node in sorted(os.listdir(kfd_root), key=lambda s: int(s) if s.isdigit() else 1 << 30):
+            try:
+                with open(os.path.join(kfd_root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0 and "drm_render_minor" in props:
+                gpus.append(int(props["drm_render_minor"]))
+        if os.path.isdir(dri_root):
+            gpus = [m for m in gpus if os.access(os.path.join(dri_root, f"renderD{m}"), os.R_OK | os.W_OK)]
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            val = environ.get(var)
+            if val:
+                idx = [v.strip() for v in val.split(",") if v.strip() != ""]
+                if not all(v.isdigit() for v in idx):
+                    return None, None                       # UUID form: the order cannot be resolved from here
+                gpus = [gpus[int(v)] for v in idx if int(v) < len(gpus)]
+        if not 0 <= local_rank < len(gpus):
+            return None, None
+        dev = os.path.join(drm_root, f"renderD{gpus[local_rank]}", "device")
+        with open(os.path.join(dev, "numa_node")) as f:
+            node = int(f.read().strip())
+        pci = os.path.basename(os.path.realpath(dev))
+        return (node if node >= 0 else None), pci
+    except (OSError, ValueError, IndexError):
+        return None, None
+
+
+def bind_to_gpu_numa(local_rank: int, node_root: str = "/sys/devices/system/node", **sysfs) -> dict:
+    """Pin this process (the calling thread; thread pools created afterwards inherit it) to the host CPUs of the NUMA
+    node its GPU hangs off, before anything touches the GPU: a rank's launch thread, its RCCL proxy thread and its
+    pinned staging buffers then sit next to its own device on a two-socket, 8-GPU node.  A no-op (reported as such)
+    when the node cannot be determined, has no CPUs this process may run on, or the platform has no affinity call.
+    Returns ``{"numa_node", "pci", "cpus"}`` for the bench line."""
+    info = {"numa_node": None, "pci": None, "cpus": None}
+    node, pci = gpu_numa_node(local_rank, **sysfs)
+    info["pci"] = pci
+    if node is None or not hasattr(os, "sched_setaffinity"):
+        return info
+    try:
+        with open(os.path.join(node_root, f"node{node}", "cpulist")) as f:
+            want = _parse_cpulist(f.read())
+        allowed = want & os.sched_getaffinity(0)
+        if not allowed:
+            return info
+        os.sched_setaffinity(0, allowed)
+        info["numa_node"], info["cpus"] = node, len(allowed)
+    except (OSError, ValueError):
+        pass
+    return info

@@ -128,3 +128,25 @@ def test_stream_shard_bookkeeping_matches_score_stream_contract():
             for j, tot in enumerate(shards[0][1]):
                 assert sum(s[0][j].shape[0] for s in shards) == tot
             assert sum(shards[0][1]) == total
+
+
+def _records_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        recs = cdist.gather_rank_records({"rank": rank, "device": rank, "numa_node": -1, "ms_per_step": 0.65 + rank,
+                                          "k1_ms": 0.27, "cls_ms": 0.38, "collectives_started": 3 + rank,
+                                          "collectives_finished": 3 + rank}, "cpu")
+        assert [r["rank"] for r in recs] == list(range(world)) and [r["device"] for r in recs] == list(range(world))
+        assert all(isinstance(r["device"], int) and isinstance(r["ms_per_step"], float) for r in recs)
+        assert recs[world - 1]["ms_per_step"] == pytest.approx(0.65 + world - 1)
+        assert recs[1]["collectives_started"] == 4 and recs[0]["numa_node"] == -1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_records_are_gathered_in_rank_order_gloo(world):
+    """bench.py's N > 1 line: every rank's own device / clock / kernel times / exchange counters."""
+    mp.spawn(_records_worker, args=(world, _free_port()), nprocs=world, join=True)

@@ -192,6 +192,66 @@ def test_visible_gpu_count_reads_sysfs_without_the_runtime(tmp_path):
     assert visible_gpu_count(str(tmp_path / "absent"), environ={}) is None
 
 
+def _fake_node(tmp_path, gpus):
+    """A sysfs look-alike: 2 CPU nodes + GPUs [(render minor, pci, numa node)], plus NUMA cpulists."""
+    nodes, drm, numa = tmp_path / "nodes", tmp_path / "drm", tmp_path / "node"
+    for i in range(2):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for j, (minor, pci, node) in enumerate(gpus):
+        d = nodes / str(2 + j)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {minor}\n")
+        pdev = tmp_path / "pci" / pci
+        pdev.mkdir(parents=True)
+        (pdev / "numa_node").write_text(f"{node}\n")
+        (drm / f"renderD{minor}").mkdir(parents=True)
+        os.symlink(pdev, drm / f"renderD{minor}" / "device")
+    return dict(kfd_root=str(nodes), drm_root=str(drm), dri_root=str(tmp_path / "no_dri")), numa
+
+
+def test_gpu_numa_node_follows_kfd_order_and_visible_devices(tmp_path):
+    """rank -> GPU -> PCI function -> NUMA node from sysfs only (no runtime call)."""
+    from cough_detector_amd.hostcpu import explicit_device_limit, gpu_numa_node
+    sysfs, _ = _fake_node(tmp_path, [(128, "0000:05:00.0", 0), (129, "0000:15:00.0", 0), (130, "0000:85:00.0", 1),
+                                     (131, "0000:95:00.0", -1)])
+    assert gpu_numa_node(0, environ={}, **sysfs) == (0, "0000:05:00.0")
+    assert gpu_numa_node(2, environ={}, **sysfs) == (1, "0000:85:00.0")
+    assert gpu_numa_node(3, environ={}, **sysfs) == (None, "0000:95:00.0")        # numa_node -1: unknown
+    assert gpu_numa_node(4, environ={}, **sysfs) == (None, None)                  # no such device
+    assert gpu_numa_node(0, environ={"HIP_VISIBLE_DEVICES": "2,0"}, **sysfs) == (1, "0000:85:00.0")
+    assert gpu_numa_node(0, environ={"ROCR_VISIBLE_DEVICES": "1,2", "HIP_VISIBLE_DEVICES": "1"}, **sysfs) == (1, "0000:85:00.0")
+    assert gpu_numa_node(0, environ={"ROCR_VISIBLE_DEVICES": "GPU-deadbeef"}, **sysfs) == (None, None)
+    assert explicit_device_limit({}) is None and explicit_device_limit({"HIP_VISIBLE_DEVICES": "0,1,2"}) == 3
+    assert explicit_device_limit({"ROCR_VISIBLE_DEVICES": "0,1", "HIP_VISIBLE_DEVICES": "0,1,2"}) == 2
+    assert explicit_device_limit({"CUDA_VISIBLE_DEVICES": ""}) == 0
+
+
+def test_bind_to_gpu_numa_sets_the_affinity_of_the_node(tmp_path):
+    from cough_detector_amd.hostcpu import bind_to_gpu_numa
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no affinity call on this platform")
+    before = os.sched_getaffinity(0)
+    cpus = sorted(before)
+    sysfs, numa = _fake_node(tmp_path, [(128, "0000:05:00.0", 0), (129, "0000:85:00.0", 1)])
+    (numa / "node0").mkdir(parents=True)
+    (numa / "node1").mkdir(parents=True)
+    half = cpus[:max(1, len(cpus) // 2)]
+    (numa / "node0" / "cpulist").write_text(f"{half[0]}-{half[-1]}\n")
+    (numa / "node1" / "cpulist").write_text("100000-100007\n")                   # CPUs this process may not use
+    try:
+        info = bind_to_gpu_numa(0, node_root=str(numa), environ={}, **sysfs)
+        assert info == {"numa_node": 0, "pci": "0000:05:00.0", "cpus": len(set(range(half[0], half[-1] + 1)) & before)}
+        assert os.sched_getaffinity(0) == set(range(half[0], half[-1] + 1)) & before
+        os.sched_setaffinity(0, before)
+        info = bind_to_gpu_numa(1, node_root=str(numa), environ={}, **sysfs)      # empty intersection: left alone
+        assert info["numa_node"] is None and os.sched_getaffinity(0) == before
+        info = bind_to_gpu_numa(5, node_root=str(numa), environ={}, **sysfs)      # unknown device: left alone
+        assert info == {"numa_node": None, "pci": None, "cpus": None} and os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_effective_dtype_reports_the_kernels_that_run():
     """A reduced-precision request the compiled kernels do not cover is reported (and warned about at the first
     forward, tests/test_gpu_fuzz.py), not silently replaced."""

@@ -14,7 +14,7 @@ python bench.py --steps 200 --cpu-seconds 0 --dtype bf16_approx > $OUT/bench_bf1
 python bench.py --steps 50 --cpu-seconds 0 --dtype fp32 > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err && \
 python bench.py --total-clips 1000000 --cpu-seconds 0 > $OUT/bench_total_1M.json 2> $OUT/bench_total_1M.err && \
 COUGH_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err && \
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_multirank_check.py > $OUT/rccl_check_1rank.txt 2>&1 && \
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tests/multirank_check.py > $OUT/rccl_check_1rank.txt 2>&1 && \
 python bench_streaming.py --streams 64 --seconds 20 > $OUT/streaming_64.jsonl 2> $OUT/streaming_64.err && \
 bash tools/prof_stats.sh $TAG/prof_stats bench.py --steps 200 --warmup 10 --cpu-seconds 0 > $OUT/prof_stats.txt 2>&1 && \
 bash tools/prof_stats.sh $TAG/prof_stats_stft tools/bench_stft.py --launches 200 --rounds 1 > $OUT/prof_stats_stft.txt 2>&1 && \
