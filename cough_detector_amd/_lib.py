@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.s
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1
 SPEC_MAGNITUDE, SPEC_FULL_WINDOW = 1, 2
-DTYPE_FP32, DTYPE_BF16, _DTYPE_DIRECT, DTYPE_BF16X3 = 0, 1, 2, 3
-DTYPES = {"fp32": DTYPE_FP32, "bf16_approx": DTYPE_BF16, "_direct": _DTYPE_DIRECT, "bf16x3": DTYPE_BF16X3}
+DTYPE_FP32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 3
+DTYPES = {"fp32": DTYPE_FP32, "bf16_approx": DTYPE_BF16, "bf16x3": DTYPE_BF16X3}
 APPROX_NOTE = ("compute_dtype='bf16' selects the APPROXIMATE single-bf16 mode (bf16 operands and activations): at a trained "
                "head's scale its logits are 0.05-0.3 away from the f32 reference, far outside the 1e-3 parity tolerance. "
                "Pass 'bf16_approx' to say that is intended; the parity-grade modes are 'bf16x3' (residual net) and 'fp32'.")

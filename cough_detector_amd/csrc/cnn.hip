@@ -364,7 +364,7 @@ struct CnnX3Args {
 
 template <int CIN, int NT, int MW, bool POOL>
 __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
-    constexpr int CH = CIN / 8, QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1;
+    constexpr int QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int clip = blockIdx.x / a.n_bands, band = blockIdx.x - clip * a.n_bands;

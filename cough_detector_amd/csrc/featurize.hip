@@ -565,6 +565,7 @@ struct cough_featurizer {
     int nfeat;           // rows of the feature image
     int nbase;           // rows the featurise kernel writes (mel [+ MFCC, delta, delta-delta])
     cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
+    int n_cus;           // compute units of the device the featuriser was created on
 };
 
 extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
@@ -633,6 +634,8 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     if (e == hipSuccess) e = hipMemcpy(f->d_tables, &t, sizeof(FeatTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&f->d_win_full, NFFT * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(f->d_win_full, hann.data(), NFFT * sizeof(float), hipMemcpyHostToDevice);
+    // per-device kernel attributes (the persistent STFT kernel's 162 KB of dynamic LDS) on the creator's device
+    if (e == hipSuccess && stft_prepare_device(&f->n_cus) != COUGH_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
         set_error("cough_featurizer_create: %s", hipGetErrorString(e));
         if (f->d_tables) (void)hipFree(f->d_tables);
@@ -665,7 +668,7 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
     const char* base = reinterpret_cast<const char*>(f->d_tables);
     return StftView{reinterpret_cast<const float*>(base + offsetof(FeatTables, win)), f->d_win_full,
                     reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw256)),
-                    reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw512))};
+                    reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw512)), f->n_cus};
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 bool featurizer_stem_fusable(const cough_featurizer* f) {
@@ -688,19 +691,6 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
     const StemFuse none{nullptr, nullptr, nullptr, 0};
-#ifdef COUGH_EXP_OVERLAP
-    // diagnostic build only (tools/exp_coresident.py): claim more LDS than the kernel uses, so that fewer featurise
-    // workgroups fit a CU and a residual-block workgroup of another stream can sit beside them
-    if (stem && stem->x3 && getenv("COUGH_EXP_K1_LDS")) {
-        const size_t lds = size_t(atoi(getenv("COUGH_EXP_K1_LDS")));
-        COUGH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(featurize_kernel<false, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, lds, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
-        COUGH_HIP_CHECK(hipGetLastError());
-        return COUGH_OK;
-    }
-#endif
     if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);

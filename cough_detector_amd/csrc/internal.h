@@ -32,6 +32,7 @@ struct StftView {
     const float* win_full;   // [512] periodic Hann(512) (T.SpectralCentroid's default window)
     const float2* tw256;     // [16][16] W256^(j*k1)
     const float2* tw512;     // [128] W512^k
+    int n_cus;               // compute units of the featuriser's device (grid of the persistent STFT kernel)
 };
 StftView featurizer_stft_view(const cough_featurizer* f);
 // spectrogram.hip: spectral-contrast + centroid rows [row0, row0 + n_bands + 1) of d_feat ([n][nfeat][101])
@@ -43,6 +44,9 @@ size_t contrast_workspace_bytes(int n_clips);
 int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
                     int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
                     hipStream_t stream);
+// spectrogram.hip: per-device set-up of the persistent STFT kernel (its 162 KB dynamic-LDS attribute) on the CURRENT
+// device + that device's CU count; cough_featurizer_create calls it
+int stft_prepare_device(int* n_cus);
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream);
 

@@ -57,23 +57,5 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
     lo.y = pk_bf16(c - __uint_as_float(hi.y << 16), d - __uint_as_float(hi.y & 0xffff0000u));
 }
 
-// Two consecutive 32x32x16 A-operand fragments a (k-step 2q) and b (2q + 1) of a 32-row tile -> the 16x16x32 fragment of
-// its lower (half == 0) or upper 16 rows for the 32-wide k-step q.  Lane (r, h) of a / b holds row r, k-chunk h; lane
-// (i, c) of the result holds row 16 half + i, k-chunk c of 4.  Per dword: v_permlane32_swap (lanes 32-63 of the first
-// with lanes 0-31 of the second), then v_permlane16_swap (odd 16-lane rows of the first with even rows of the second).
-__device__ __forceinline__ bf16x8 tail_swap(bf16x8 a, bf16x8 b, int half) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
-    u32x4 lo4, hi4;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const auto r = __builtin_amdgcn_permlane32_swap(ua[d], ub[d], false, false);
-        const auto t = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false);
-        lo4[d] = t[0];
-        hi4[d] = t[1];
-    }
-    return __builtin_bit_cast(bf16x8, half ? hi4 : lo4);
-}
-
 }  // namespace
 }  // namespace cough

@@ -93,9 +93,6 @@ struct RbxCfg {
     static constexpr int HRED = BIAS + 2 * COUT * 4;                         // head reduction scratch [WAVES][2] f32
     static constexpr int LDS = HRED + WAVES * 2 * 4;
     static constexpr int OP = COUT + 4;                                      // floats per row of the f32 output tile
-    // pre-split image of ONE clip of this block's INPUT in HBM (RBX_A2_PRESPLIT): [hi, lo][CHI chunk planes][NPP cells] x 16 B
-    static constexpr int IMG1 = 2 * XH * OW;                                 // cells of one clip in one chunk plane (= NPP / G)
-    static constexpr int IMGB = 2 * CHI * IMG1 * 16;                         // bytes per clip
     static_assert(WAVES % NT == 0 && MG * MW * 32 + (TAIL ? 16 : 0) >= M, "tile split");
     static_assert(OW == (XW + 1) / 2, "sub-image row pitch");
     static_assert(M * OP * 4 <= 2 * PL, "the output tile lies over the planes");
@@ -120,20 +117,6 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
 #endif
 #ifndef RBX_PRIO
 #define RBX_PRIO 0
-#endif
-#ifndef RBX_A2_PRESPLIT
-#define RBX_A2_PRESPLIT 0   // 1 (experiment, correct, NO GAIN): block 0 stores its output already split (hi, lo bf16 pairs: the
-                            // same 4 bytes per value, the same rounding point, so block 1's operands and the logits are
-                            // bit-identical) and in block 1's LDS plane order; block 1 then stages its input with plain 16-byte
-                            // copies -- no split, one ds_write_b128 per piece.  cls 0.3854 -> 0.3886 ms
-                            // (profiles/r03_resblock_experiments.txt (h)): the staging phase is bound by arrival, not by its
-                            // instructions
-#endif
-#ifndef RBX_TAIL_SWAP
-#define RBX_TAIL_SWAP 0   // 1 (experiment, correct, SLOWER): the 16-row tile's 16x16x32 weight fragments are re-arranged from the
-                          // 32x32x16 fragments the wave already holds (v_permlane32_swap + v_permlane16_swap) instead of being
-                          // streamed a second time from L2 -- removes 29 % of the kernel's L1 accesses and costs +2-3 % of the
-                          // classifier time (profiles/r03_resblock_experiments.txt): the k-loop is issue-bound, not L1-bound
 #endif
     constexpr int D = RBX_D;   // weight prefetch depth (k-steps; one k-step = MW x 3 MFMAs >= 192 cycles)
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -160,43 +143,17 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     for (int i = 0; i < D; ++i) { ring[i][0] = wfrag(i, 0); ring[i][1] = wfrag(i, 1); }
     // TAIL: this wave's 16 channels (tile `wave`) of the 16-row tile, in k32-steps
     constexpr int DT = D / 2 > 0 ? D / 2 : 1;
-    const bf16_t* wtbase = (TAIL && !RBX_TAIL_SWAP) ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
+    const bf16_t* wtbase = TAIL ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
     auto wtfrag = [&](int q, int plane) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(wtbase + (size_t(q) * Cfg::WAVES * 2 + plane) * 512);
     };
     bf16x8 tring[DT][2];
-    if constexpr (TAIL && !RBX_TAIL_SWAP) {
+    if constexpr (TAIL) {
 #pragma unroll
         for (int i = 0; i < DT; ++i) { tring[i][0] = wtfrag(i, 0); tring[i][1] = wtfrag(i, 1); }
     }
-    // TAIL: the 16 output channels this wave owns in the 16-row tile.  With RBX_TAIL_SWAP they are the half `mg` of the
-    // wave's own 32-channel tile `ng` (so that its weights are the ones already in its ring); otherwise tile `wave`.
-    const int tch = RBX_TAIL_SWAP ? 32 * ng + 16 * mg : 16 * wave;
+    const int tch = 16 * wave;   // TAIL: the 16 output channels this wave owns in the 16-row tile
 
-    if constexpr (RBX_A2_PRESPLIT && CIN == 64) {
-        // ---- stage (pre-split input, written by block 0 in this kernel's plane order): per clip a linear run of 16-byte
-        // cells [hi, lo][chunk][cell]; each goes to cell (g * NPP + cell) of its chunk plane as it is ----
-        constexpr int IMG1 = Cfg::IMG1, PERCLIP = 2 * CHI * IMG1, NPIECE = G * PERCLIP, UN = (NPIECE + THREADS - 1) / THREADS;
-        static_assert(UN <= 20, "staging registers");
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.x) + (long long)clip0 * Cfg::IMGB);
-        const int valid = nvalid * PERCLIP;
-        uint4 v[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = tid + u * THREADS;
-            v[u] = src[i < valid ? i : valid - 1];
-        }
-        if (tid < 2 * CHI) *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = tid + u * THREADS;
-            if (i < NPIECE) {
-                const int g = i / PERCLIP, rem = i % PERCLIP, pl = rem / (CHI * IMG1), q = (rem % (CHI * IMG1)) / IMG1, c = rem % IMG1;
-                if (i >= valid) v[u] = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(smem + pl * PL + q * CPX + (g * NPP + c) * 16) = v[u];
-            }
-        }
-    } else {
     // ---- stage: the clips' x (f32) is one linear run of 16-byte pieces = 4 channels of one pixel; all loads are
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
     {
@@ -230,7 +187,6 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 *reinterpret_cast<uint2*>(smem + off + PL) = lo;
             }
         }
-    }
     }
     if (tid < COUT) { lbias[tid] = bv1; lbias[COUT + tid] = bv2; }
     float fw0 = 0.f, fw1 = 0.f, fb0 = 0.f, fb1 = 0.f;   // fused head (block 1): Linear(128, 2) weights of channel tid & 127
@@ -286,7 +242,6 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
         for (int mt = 0; mt < MWX; ++mt) { acc1[mt] = f32x16{0}; acc2[mt] = f32x16{0}; }
         f32x4 tacc1 = {0.f, 0.f, 0.f, 0.f}, tacc2 = {0.f, 0.f, 0.f, 0.f};
         bf16x8 taf[2];
-        bf16x8 tw_prev[2] = {};   // RBX_TAIL_SWAP: the (hi, lo) weight fragments of the even k-step, kept for the odd one
         int ttadr = 0;
         // TAIL fragments of k32-step q (q counts 32-wide steps through conv1, projection, conv2)
         auto tfrag = [&](auto qc) {
@@ -415,18 +370,6 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             // free.  Left alone, the scheduler sinks every ds_read next to its MFMA and each pays the LDS latency; one
             // filler group per MFMA triple (the first version) left the pipe idle behind every third MFMA (+2.3 %).
             const bf16x8 whi = ring[s % D][0], wlo = ring[s % D][1];
-            bf16x8 tsw_hi = {}, tsw_lo = {};
-            if constexpr (TAIL && RBX_TAIL_SWAP) {
-                if constexpr (s % 2 == 0) {
-                    tw_prev[0] = whi;
-                    tw_prev[1] = wlo;
-                } else {
-                    // re-arranged here, at the head of the odd step, so that the 16 lane swaps issue in the shadow of the
-                    // 32-row tiles' MFMAs instead of in front of the 16-row tile's
-                    tsw_hi = tail_swap(tw_prev[0], whi, mg);
-                    tsw_lo = tail_swap(tw_prev[1], wlo, mg);
-                }
-            }
 #pragma unroll
             for (int mt = 0; mt < MWX; ++mt) {
                 constexpr bool pf = s + 1 < KS && s + 1 != KS1 + KSP;
@@ -457,20 +400,8 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 if constexpr (s % 2 == 0) {
                     tfrag(std::integral_constant<int, q>{});
                 } else {
-                    bf16x8 twhi, twlo;
-                    if constexpr (RBX_TAIL_SWAP) {
-                        // A = fragment of k-step 2q (tw_prev), B = that of 2q + 1 (this step's): lane (r, h) holds
-                        // W[32 ng + r][16 s + 8 h ..].  As 16-lane rows A = (A0 A1 A2 A3): A0 / A1 = channels 0-15 / 16-31 at
-                        // h = 0, A2 / A3 at h = 1.  A 16x16x32 fragment wants lane (i, c) = W[16 t + i][32 q + 8 c ..]:
-                        // rows (A0 A2 B0 B2) for the lower 16 channels, (A1 A3 B1 B3) for the upper.  permlane32_swap(A, B)
-                        // gives (A0 A1 B0 B1), (A2 A3 B2 B3); permlane16_swap of those two gives exactly the two wanted.
-                        twhi = tsw_hi;
-                        twlo = tsw_lo;
-                    } else {
-                        twhi = tring[q % DT][0];
-                        twlo = tring[q % DT][1];
-                        if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
-                    }
+                    const bf16x8 twhi = tring[q % DT][0], twlo = tring[q % DT][1];
+                    if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
 #if RBX_PIN
                     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -532,27 +463,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     __syncthreads();
     RB_STAMP(6);
     const float* otile = reinterpret_cast<const float*>(smem);
-    if constexpr (RBX_A2_PRESPLIT && COUT == 64) {
-        // the next block's input image: (pixel, 8-channel chunk) -> one hi cell and one lo cell, at the pixel's place in
-        // the parity-split order of the NEXT block (row pitch of its output image)
-        static_assert(G == 1, "one clip per workgroup");
-        constexpr int OW2 = (OW + 1) / 2, RE2 = (OH + 1) / 2, RO2 = OH / 2;             // next block: OW, even / odd rows
-        constexpr int B01 = RE2 * OW2, B10 = 2 * RE2 * OW2, B11 = 2 * RE2 * OW2 + RO2 * OW2, IMG2 = 2 * OH * OW2;
-        if (a.out != nullptr && nvalid > 0) {
-            char* o = reinterpret_cast<char*>(a.out) + (long long)clip0 * (2 * CHO * IMG2 * 16);
-            for (int p = tid; p < PER * CHO; p += THREADS) {
-                const int row = p / CHO, q = p % CHO, oh = row / OW, ow = row % OW;
-                const int cell = ((oh & 1) ? ((ow & 1) ? B11 : B10) : ((ow & 1) ? B01 : 0)) + (oh >> 1) * OW2 + (ow >> 1);
-                const float4 v0 = *reinterpret_cast<const float4*>(otile + row * OP + 8 * q);
-                const float4 v1 = *reinterpret_cast<const float4*>(otile + row * OP + 8 * q + 4);
-                uint2 h0, l0, h1, l1;
-                split4(v0.x, v0.y, v0.z, v0.w, h0, l0);
-                split4(v1.x, v1.y, v1.z, v1.w, h1, l1);
-                *reinterpret_cast<uint4*>(o + (q * IMG2 + cell) * 16) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                *reinterpret_cast<uint4*>(o + ((CHO + q) * IMG2 + cell) * 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-            }
-        }
-    } else if (a.out != nullptr) {
+    if (a.out != nullptr) {
         const int nvec = nvalid * PER * (COUT / 4);
         float4* o = reinterpret_cast<float4*>(a.out + (long long)clip0 * PER * COUT);
         for (int p = tid; p < nvec; p += THREADS) {

@@ -14,9 +14,6 @@
 //             the projection skip is appended to the K loop of conv2, so skip / add / ReLU cost no
 //             extra pass.  FP32: v_mfma_f32_32x32x2_f32; BF16: v_mfma_f32_32x32x16_bf16, f32 accumulate.
 //   K5 tail   global mean over HxW -> Linear(128,2) -> optional softmax / argmax.
-//
-// A third "direct" path (plain f32 FMA loops, one thread per output) exists only as an on-device
-// cross-check of the MFMA index math; the Python surface never selects it.
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
@@ -33,8 +30,6 @@
 #include "nn_common.h"
 #include "conv_gemm.h"
 #include "resblock_x3.h"
-
-#define COUGH_DTYPE_DIRECT 2
 
 namespace cough {
 namespace {
@@ -226,30 +221,6 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
             }
         }
     }
-}
-
-template <typename T>
-__global__ void stem_direct_kernel(const float* __restrict__ feat, int H, int W, int P1h, int P1w, long long n_pool,
-                                   const float* __restrict__ wk, const float* __restrict__ bias, T* __restrict__ out) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_pool * STEM_N) return;
-    const int n = int(idx % STEM_N);
-    const long long P = idx / STEM_N;
-    const int per_clip = P1h * P1w;
-    const int b = int(P / per_clip), rem = int(P - (long long)b * per_clip), ph = rem / P1w, pw = rem - ph * P1w;
-    const float* src = feat + (long long)b * H * W;
-    float best = -INFINITY;
-    for (int dy = 0; dy < 2; ++dy)
-        for (int dx = 0; dx < 2; ++dx) {
-            const int ih0 = 2 * (2 * ph + dy) - 3, iw0 = 2 * (2 * pw + dx) - 3;
-            float acc = 0.f;
-            for (int k = 0; k < STEM_K; ++k) {
-                const int ih = ih0 + k / 7, iw = iw0 + k % 7;
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W) acc = fmaf(src[ih * W + iw], wk[k * STEM_N + n], acc);
-            }
-            best = fmaxf(best, acc);
-        }
-    out[idx] = from_f32<T>(fmaxf(best + bias[n], 0.f));
 }
 
 // ------------------------------------------------------------------------------------ K3/K4 convs
@@ -684,33 +655,6 @@ __global__ __launch_bounds__(WAVES * 64) void resblock_bf16_kernel(RbArgs a) {
     RB_STAMP(6);
 }
 
-template <typename T>
-__global__ void conv_direct_kernel(ConvArgs<T> a) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.M * a.N) return;
-    const int n = int(idx % a.N);
-    const long long m = idx / a.N;
-    const int per = a.OH * a.OW;
-    const int b = int(m / per), rem = int(m - (long long)b * per), oh = rem / a.OW, ow = rem - oh * a.OW;
-    const T* w = a.wp + (long long)n * a.Ktot;
-    float acc = 0.f;
-    int kbase = 0;
-    for (int kh = 0; kh < a.KH; ++kh)
-        for (int kw = 0; kw < a.KW; ++kw) {
-            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
-            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-                const T* ap = a.in + (((long long)b * a.H + ih) * a.W + iw) * a.C;
-                for (int c = 0; c < a.C; ++c) acc = fmaf(to_f32<T>(ap[c]), to_f32<T>(w[kbase + c]), acc);
-            }
-            kbase += a.C;
-        }
-    if (a.C2 > 0) {
-        const T* ap = a.in2 + (((long long)b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.C2;
-        for (int c = 0; c < a.C2; ++c) acc = fmaf(to_f32<T>(ap[c]), to_f32<T>(w[kbase + c]), acc);
-    }
-    a.out[idx] = from_f32<T>(fmaxf(acc + a.bias[n], 0.f));
-}
-
 // ------------------------------------------------------------------------------------ K5 tail
 template <typename T>
 __global__ __launch_bounds__(128) void tail_kernel(const T* __restrict__ a3, int HW, const float* __restrict__ fcw,
@@ -929,29 +873,11 @@ Workspace carve(const cough_resnet* m, char* base, int n, const Shapes& s) {
     auto take = [&](size_t elems) { char* p = base + off; off += align256(elems * m->esize); return p; };
     w.a1 = take(size_t(n) * s.P1h * s.P1w * 32);
     w.h0 = take(size_t(n) * s.B0h * s.B0w * 64);
-    // bf16x3, shipped image: block 0 hands a2 over pre-split in block 1's LDS plane order (RBX_A2_PRESPLIT): hi + lo
-    // cells incl. the parity-split pad cells, 39 424 B per clip instead of 36 608
-    size_t a2_elems = size_t(n) * s.B0h * s.B0w * 64;
-    if (RBX_A2_PRESPLIT && m->dtype == COUGH_DTYPE_BF16X3 && s.P1h == 22 && s.P1w == 25)
-        a2_elems = std::max(a2_elems, size_t(n) * (RbxCfg<64, 128, 2, 11, 13>::IMGB / 4));
-    w.a2 = take(a2_elems);
+    w.a2 = take(size_t(n) * s.B0h * s.B0w * 64);
     w.h1 = take(size_t(n) * s.B1h * s.B1w * 128);
     w.a3 = take(size_t(n) * s.B1h * s.B1w * 128);
     w.total = off;
     return w;
-}
-
-// parity tap of the pre-split a2 image (block 1's plane order, RbxCfg<64, 128, 2, 11, 13>) -> NCHW f32, value = hi + lo
-__global__ void presplit_to_nchw_kernel(const unsigned char* __restrict__ planes, float* __restrict__ out, long long total) {
-    using Cfg = RbxCfg<64, 128, 2, 11, 13>;
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= total) return;
-    const int w = int(i % 13), h = int((i / 13) % 11), c = int((i / 143) % 64);
-    const long long n = i / (143 * 64);
-    const int cell = ((h & 1) ? ((w & 1) ? Cfg::PB11 : Cfg::PB10) : ((w & 1) ? Cfg::PB01 : 0)) + (h >> 1) * Cfg::OW + (w >> 1);
-    const bf16_t* img = reinterpret_cast<const bf16_t*>(planes + n * Cfg::IMGB);
-    const int e = ((c >> 3) * Cfg::IMG1 + cell) * 8 + (c & 7);
-    out[i] = bf2f(img[e]) + bf2f(img[Cfg::CHI * Cfg::IMG1 * 8 + e]);
 }
 
 // ------------------------------------------------------------------------------ generic channel tuples (f32)
@@ -1048,10 +974,7 @@ void pad_folded(const FoldedConv& f, int Np, int Cp, std::vector<float>& w, int 
 template <typename T>
 int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     if (a.M == 0) return COUGH_OK;
-    if (m->dtype == COUGH_DTYPE_DIRECT) {
-        const long long total = a.M * a.N;
-        hipLaunchKernelGGL(conv_direct_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
-    } else if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
         const dim3 grid((unsigned)((a.M + CG_BM - 1) / CG_BM));
         if (a.N == 64) hipLaunchKernelGGL((conv_gemm_bf16_kernel<2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<4>), grid, dim3(256), 0, st, a);
@@ -1072,9 +995,6 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     const long long n_pool = (long long)n * s.P1h * s.P1w;
     if (stem_done) {
         // a1 was produced by the featurise kernel (cough_pipeline_forward)
-    } else if (m->dtype == COUGH_DTYPE_DIRECT) {
-        hipLaunchKernelGGL(stem_direct_kernel<T>, dim3((unsigned)((n_pool * 32 + 255) / 256)), dim3(256), 0, st, d_feat,
-                           s.H, s.W, s.P1h, s.P1w, n_pool, m->d_stem_w, m->d_stem_b, reinterpret_cast<T*>(w.a1));
     } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
@@ -1196,8 +1116,7 @@ extern "C" int cough_debug_set_rb_stamp_buffer(void* d_buf) {
 extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype) {
     using namespace cough;
     COUGH_REQUIRE(out && w, COUGH_EINVAL, "cough_resnet_create: NULL argument");
-    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_DIRECT ||
-                      dtype == COUGH_DTYPE_BF16X3, COUGH_EINVAL,
+    COUGH_REQUIRE(dtype == COUGH_DTYPE_FP32 || dtype == COUGH_DTYPE_BF16 || dtype == COUGH_DTYPE_BF16X3, COUGH_EINVAL,
                   "cough_resnet_create: unknown dtype %d", dtype);
     const cough_conv_bn* all[7] = {&w->stem, &w->block[0].conv1, &w->block[0].conv2, &w->block[0].skip,
                                    &w->block[1].conv1, &w->block[1].conv2, &w->block[1].skip};
@@ -1428,15 +1347,6 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
     COUGH_REQUIRE(which >= 1 && which <= 3, COUGH_EINVAL, "cough_resnet_read_activation: which must be 1..3");
     const Shapes s = make_shapes(height, width);
     const Workspace w = carve(m, const_cast<char*>(static_cast<const char*>(d_workspace)), n_clips, s);
-    if (which == 2 && RBX_A2_PRESPLIT && m->dtype == COUGH_DTYPE_BF16X3 && s.P1h == 22 && s.P1w == 25) {
-        // a2 lives as block 1's pre-split plane image: value = hi + lo (16 significant bits of the f32 activation)
-        const long long total = (long long)n_clips * 64 * 11 * 13;
-        if (total == 0) return COUGH_OK;
-        hipLaunchKernelGGL(presplit_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned char*>(w.a2), d_out, total);
-        COUGH_HIP_CHECK(hipGetLastError());
-        return COUGH_OK;
-    }
     const char* src = which == 1 ? w.a1 : which == 2 ? w.a2 : w.a3;
     const int C = which == 1 ? 32 : which == 2 ? 64 : 128;
     const int HW = which == 1 ? s.P1h * s.P1w : which == 2 ? s.B0h * s.B0w : s.B1h * s.B1w;
@@ -1493,15 +1403,6 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
     if (can_fuse_stem(f, m)) {
         const Workspace w = carve(m, ws, n_clips, s);
         const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, w.a1, m->dtype == COUGH_DTYPE_BF16X3 ? 1 : 0};
-#ifdef COUGH_EXP_OVERLAP
-        // diagnostic build only (tools/exp_coresident.py): run one half of the pipeline (timing experiments on two streams)
-        const char* only = getenv("COUGH_EXP_ONLY");
-        if (only && only[0] == 'b') {   // "blocks": a1 is whatever an earlier launch left in this workspace
-            if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
-            return forward_impl<bf16_t>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);
-        }
-        if (only && only[0] == 'k') return launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st);
-#endif
         if (int e = launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st)) return e;
         if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
         if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);

@@ -12,15 +12,11 @@
 // stages it in LDS as the linear image it is in memory and writes it with aligned 16-byte stores; samples arrive by
 // LDS-DMA.  0.169 ms for 4096 clips = 51 % of 8 TB/s, PMC traffic 1.001x (profiles/r03_stft_experiments.txt).
 //
-// stft_kernel (first below) is the round-1/2 design, kept behind COUGH_STFT_V1 for same-box A/B only: one 4-wave
-// workgroup per (clip, chunk of 7/7/6/6 four-frame groups = 28/28/24/21 frames), three resident per CU.  A wave
-// transforms 4 frames at a time (16 lanes each): lane j of a frame ends up with Z[j+16*k2]; with its partner's
+//
+// A wave transforms 4 frames at a time (16 lanes each): lane j of a frame ends up with Z[j+16*k2]; with its partner's
 // Z[256-k] it forms both X[k] (k = j+16*k2 < 128) and X[256-k] -- conj(E - W^k O) -- so every bin 0..256 comes out of
-// the same 8 butterflies.  The (bin, time) output is time-minor, so the chunk's powers are staged in LDS and flushed
-// as ~100-byte row fragments; the four chunks of a clip sit on workgroup ids 8 apart (same XCD, dispatched together)
-// so that the fragments of one 404-byte row meet in that XCD's L2 (WRITE_SIZE 1.004x; 0.2445 ms = 35 %).
-#include <cstdlib>
-
+// the same 8 butterflies.  (The round-1/2 kernel -- one 4-wave workgroup per (clip, frame chunk), sibling chunks' row
+// fragments meeting in L2, 0.2445 ms = 35 % -- is in the git history; profiles/r03_stft_experiments.txt has the A/B.)
 #include "common.h"
 #include "fft256.h"
 #include "internal.h"
@@ -30,21 +26,10 @@ namespace {
 
 constexpr int NS = 16000, NFFT = 512, HOP = 160, NFRAMES = 101, NFREQ = 257;
 constexpr int PADL = NFFT / 2;
-constexpr int THREADS = 256, WAVES = 4, FPW = 4;
+constexpr int FPW = 4;
 constexpr int NGROUP = (NFRAMES + FPW - 1) / FPW;           // 26 groups of 4 frames
-constexpr int NCHUNK = 4;
-__device__ constexpr int CHUNK_G0[NCHUNK + 1] = {0, 7, 14, 20, NGROUP};   // first group of each chunk: every wave has 1-2 groups
-constexpr int CHUNK_MAX = 7 * FPW;                          // frames staged per item (<= 28)
-constexpr int XROW = 17, XFRAME = 16 * XROW;
-constexpr int FIRST_PLAIN = 2, LAST_PLAIN = 98;             // frames whose 512 samples lie inside the clip
-constexpr int PITCH = CHUNK_MAX + 1;                        // 29, odd: the 16 lanes of a frame hit 16 banks
-constexpr int FLUSH_COLS = 32;                              // flush thread layout: 32 columns x 8 rows per sweep
-constexpr size_t LDS_XCH = size_t(WAVES) * FPW * XFRAME * 4;   // 17408
-constexpr size_t LDS_PW = size_t(NFREQ) * PITCH * 4;           // 29812
-constexpr size_t LDS_TW = size_t(16) * XROW * 8;               // 2176
-constexpr size_t LDS_TOTAL = LDS_XCH + LDS_TW + LDS_PW;
-static_assert(LDS_TOTAL * 3 <= 160 * 1024, "three workgroups per CU");
-static_assert(LDS_XCH % 16 == 0 && LDS_TW % 16 == 0, "float2 table and staging rows start 16-byte aligned");
+constexpr int XROW = 17;
+constexpr size_t LDS_TW = size_t(16) * XROW * 8;               // 2176: [16][XROW] float2 twiddles
 
 #ifdef COUGH_K1_STAMPS
 // Diagnostic build only (tools/stft_stamps.py): s_memtime of wave 0 and wave 3 at phase boundaries, into a buffer of
@@ -58,159 +43,6 @@ __device__ unsigned long long* g_stft_stamp_buf = nullptr;
 #else
 #define STFT_STAMP(slot) do {} while (0)
 #endif
-
-// FULLWIN: all 512 window taps are live (Hann(512)); otherwise taps [0,56) and [456,512) are zero (Hann(400)
-// centred in the frame) and the first / last 32-sample slabs are never loaded.
-template <bool FULLWIN, bool MAG>
-__global__ __launch_bounds__(THREADS, 3) void stft_kernel(const float* __restrict__ wav, long long wav_stride,
-                                                          float* __restrict__ out, const float* __restrict__ win,
-                                                          const float2* __restrict__ tw256,
-                                                          const float2* __restrict__ tw512, int n_clips) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);
-    float2* twl = reinterpret_cast<float2*>(smem + LDS_XCH);              // [16][XROW], 8-byte aligned (ds_read2_b64)
-    float* pw = reinterpret_cast<float*>(smem + LDS_XCH + LDS_TW);        // [257][PITCH]
-    constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // workgroup id = slab * 8 + r: clip = (slab / NCHUNK) * 8 + r, chunk = slab % NCHUNK
-    const int slab = blockIdx.x >> 3;
-    const long long clip = (long long)(slab / NCHUNK) * 8 + (blockIdx.x & 7);
-    const int chunk = slab % NCHUNK;
-    const int j = lane & 15, fsub = lane >> 4;
-    const float2* tw_row = twl + j * XROW;
-    const float2 tw_j = tw512[j];
-    float* myx = xs + (wave * FPW + fsub) * XFRAME;
-
-    // 14 (16) eight-byte loads of the 4 frames of group g of the clip at xc
-    auto load_group = [&](const float* xc, int g, float2 (&raw)[16]) {
-        const int t_raw = FPW * g + fsub;
-        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames of group 25 redo the last frame
-        const int s0 = HOP * t - PADL + 2 * j;
-        if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
-#pragma unroll
-            for (int n1 = N0; n1 < N1; ++n1) raw[n1] = *reinterpret_cast<const float2*>(xc + s0 + 32 * n1);
-        } else {   // reflect padding of torch.stft(center=True)
-#pragma unroll
-            for (int n1 = N0; n1 < N1; ++n1) {
-                int i0 = s0 + 32 * n1, i1 = i0 + 1;
-                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
-                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
-                raw[n1] = make_float2(xc[i0], xc[i1]);
-            }
-        }
-    };
-    if (clip >= n_clips) return;   // workgroup-uniform: the last slab of 8 clips may be partial
-    STFT_STAMP(0);
-    float2 raw[16];
-    load_group(wav + clip * wav_stride, CHUNK_G0[chunk] + wave, raw);
-    // window taps and the W256 table arrive while the first samples are on their way from HBM
-    float w_re[16], w_im[16];
-#pragma unroll
-    for (int n1 = N0; n1 < N1; ++n1) {
-        w_re[n1] = win[32 * n1 + 2 * j];
-        w_im[n1] = win[32 * n1 + 2 * j + 1];
-    }
-    twl[(tid >> 4) * XROW + (tid & 15)] = tw256[tid];
-    __syncthreads();
-    STFT_STAMP(1);
-
-    {
-        const float* x = wav + clip * wav_stride;
-        const int gs = CHUNK_G0[chunk], ge = CHUNK_G0[chunk + 1];
-#pragma unroll 1
-        for (int g = gs + wave; g < ge; g += WAVES) {       // 1 or 2 groups per wave
-            float2 a[16];
-            if constexpr (!FULLWIN) {
-                a[0] = make_float2(0.f, 0.f);
-                a[15] = make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int n1 = N0; n1 < N1; ++n1) a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
-            // the raw registers are free: the wave's second group starts moving now and lands during this FFT
-            if (g + WAVES < ge) load_group(x, g + WAVES, raw);
-#ifdef COUGH_K1_STAMPS
-            asm volatile("" :: "v"(a[1].x));   // the window multiply has consumed the samples: they have arrived
-            if (g == gs + wave) STFT_STAMP(2);
-#endif
-            dft16(a);
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
-            float2 z[16];
-#pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].x;
-            wave_lds_fence();
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) z[n2].x = myx[j * XROW + n2];
-            wave_lds_fence();
-#pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].y;
-            wave_lds_fence();
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * XROW + n2];
-            wave_lds_fence();
-            dft16(z);   // z[k2] = Z[j + 16*k2]
-
-            float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror, then rotate right by one
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
-                rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
-            }
-            const bool live = FPW * g + fsub < NFRAMES;   // idle sub-frames of the last group store nothing
-            float* col = pw + (g - gs) * FPW + fsub;
-            auto put = [&](int bin, float pwr4) {   // pwr4 = |2X|^2
-                col[bin * PITCH] = MAG ? 0.5f * sqrtf(pwr4) : 0.25f * pwr4;
-            };
-            if (live) {
-#pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) {
-                    const float2 zk = z[k2];
-                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
-                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
-                    // 2E = Zk + conj Zp, 2O = -i (Zk - conj Zp); 2X[k] = 2E + W^k 2O, 2X[256-k] = conj(2E - W^k 2O)
-                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
-                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
-                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
-                    const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
-                    const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
-                    const int k = j + 16 * k2;
-                    put(k, ar * ar + ai * ai);
-                    put(NFFT / 2 - k, br * br + bi * bi);
-                }
-                if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
-            }
-            wave_lds_fence();
-#ifdef COUGH_K1_STAMPS
-            if (g == gs + wave) STFT_STAMP(3);
-#endif
-        }
-        STFT_STAMP(4);
-        __syncthreads();
-        STFT_STAMP(5);
-        {
-            const int t0 = gs * FPW;
-            const int nv = (ge * FPW < NFRAMES ? ge * FPW : NFRAMES) - t0;
-            float* o = out + clip * (long long)NFREQ * NFRAMES + t0;
-            constexpr int ROWS_PER_IT = THREADS / FLUSH_COLS;   // 8
-            static_assert(NFREQ == 32 * ROWS_PER_IT + 1, "flush shape");
-            const int c = tid & (FLUSH_COLS - 1), r0 = tid / FLUSH_COLS;
-            if (c < nv) {
-                const float* src = pw + r0 * PITCH + c;
-                float* dst = o + r0 * NFRAMES + c;
-#pragma unroll
-                for (int it = 0; it < 32; ++it) dst[it * ROWS_PER_IT * NFRAMES] = src[it * ROWS_PER_IT * PITCH];
-                if (r0 == 0) dst[256 * NFRAMES] = src[256 * PITCH];
-            }
-        }
-#ifdef COUGH_K1_STAMPS
-        STFT_STAMP(6);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STFT_STAMP(7);
-#endif
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // stft3_kernel: one PERSISTENT 13-wave workgroup per CU, one clip at a time, whole spectrogram staged in LDS.
@@ -351,8 +183,16 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             const int g = wave + W3 * rd;
             // this group's samples are in the scratch.  Round 0: everything but the flush stores issued after the DMA
             // (at least 7 per wave) has completed; round 1: nothing was issued after its DMA
+            // The 7: every wave issues >= 7 flush stores behind the DMA -- the flush below hands thread t pieces t,
+            // t + THREADS3, ... of the IMG_PIECES - 2 interior pieces, so the wave with the fewest gets
+            // (IMG_PIECES - 2) / THREADS3 of them.  A build without the stores has nothing behind the DMA: vmcnt(0).
+            static_assert((IMG_PIECES - 2) / THREADS3 >= 7, "round 0 waits with vmcnt(7): every wave must issue >= 7 flush stores after its DMA");
+#ifndef COUGH_STFT_NO_STORE
             if (rd == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (rd == 0) STFT3_STAMP(1);
             float2 a[16], z[16];
             if constexpr (!FULLWIN) {
@@ -435,11 +275,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
 #pragma unroll
             for (int it = 0; it < (IMG_PIECES + THREADS3 - 1) / THREADS3; ++it) {
                 const int p = tid + THREADS3 * it;
-                #ifdef COUGH_STFT_NT_STORE
-                if (p > 0 && p < last) __builtin_nontemporal_store(src[p], dst + p);
-#else
                 if (p > 0 && p < last) dst[p] = src[p];
-#endif
             }
             if (tid < 8) {   // element e of the first (tid < 4) or last piece
                 const int e = (tid < 4 ? 0 : 4 * last) + (tid & 3) - lead;
@@ -597,50 +433,31 @@ int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wa
     return COUGH_OK;
 }
 
-namespace {
-}  // namespace
-
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream) {
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const float* win = full ? v.win_full : v.win;
-    static const bool use_v1 = getenv("COUGH_STFT_V1") != nullptr;   // A/B only: the non-persistent register-staged kernel
-    if (!use_v1) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        const dim3 grid3(n_clips < cus ? n_clips : cus), block3(THREADS3);   // one persistent workgroup per CU
-#define COUGH_STFT3_LAUNCH(F, M)                                                                                         \
-    do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
-            COUGH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stft3_kernel<F, M>),                       \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS3_TOTAL));           \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
-        hipLaunchKernelGGL((stft3_kernel<F, M>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win,     \
-                           v.tw256, v.tw512, n_clips);                                                                   \
-    } while (0)
-        if (full && mag) COUGH_STFT3_LAUNCH(true, true);
-        else if (full) COUGH_STFT3_LAUNCH(true, false);
-        else if (mag) COUGH_STFT3_LAUNCH(false, true);
-        else COUGH_STFT3_LAUNCH(false, false);
-#undef COUGH_STFT3_LAUNCH
-        COUGH_HIP_CHECK(hipGetLastError());
-        return COUGH_OK;
-    }
-    const dim3 grid(((n_clips + 7) / 8) * 8 * NCHUNK), block(THREADS);   // id = (slab * NCHUNK + chunk) * 8 + clip % 8
-#define COUGH_STFT_LAUNCH(F, M)                                                                              \
-    hipLaunchKernelGGL((stft_kernel<F, M>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_spec, win, \
-                       v.tw256, v.tw512, n_clips)
-    if (full && mag) COUGH_STFT_LAUNCH(true, true);
-    else if (full) COUGH_STFT_LAUNCH(true, false);
-    else if (mag) COUGH_STFT_LAUNCH(false, true);
-    else COUGH_STFT_LAUNCH(false, false);
-#undef COUGH_STFT_LAUNCH
+    const dim3 grid3(n_clips < v.n_cus ? n_clips : v.n_cus), block3(THREADS3);   // one persistent workgroup per CU
+    // the > 64 KB dynamic-LDS attribute of the four instantiations is set per device by stft_prepare_device (called from
+    // cough_featurizer_create on the featuriser's device), not lazily here: the attribute is per device and a launch
+    // path must not carry process-wide mutable state
+    if (full && mag) hipLaunchKernelGGL((stft3_kernel<true, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
+    else if (full) hipLaunchKernelGGL((stft3_kernel<true, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
+    else if (mag) hipLaunchKernelGGL((stft3_kernel<false, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
+    else hipLaunchKernelGGL((stft3_kernel<false, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
     COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+int stft_prepare_device(int* n_cus) {
+    int dev = 0, cus = 0;
+    COUGH_HIP_CHECK(hipGetDevice(&dev));
+    COUGH_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    *n_cus = cus > 0 ? cus : 256;
+    const void* fns[4] = {reinterpret_cast<const void*>(stft3_kernel<false, false>), reinterpret_cast<const void*>(stft3_kernel<false, true>),
+                          reinterpret_cast<const void*>(stft3_kernel<true, false>), reinterpret_cast<const void*>(stft3_kernel<true, true>)};
+    for (const void* fn : fns)
+        COUGH_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS3_TOTAL));
     return COUGH_OK;
 }
 

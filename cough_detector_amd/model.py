@@ -132,7 +132,7 @@ class CoughDetectorResidual(nn.Module):
             raise ValueError("CoughDetectorResidual: channels must be 2..17 values in 1..1024")
         self.channels = channels          # (32, 64, 128): the fused kernels; any other tuple: the exact-f32 kernels
         # what was asked for ('bf16' = deprecated alias of 'bf16_approx', warns); ``effective_dtype`` is what runs
-        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16x3", "bf16_approx", "_direct"))
+        self.compute_dtype = _lib.normalize_dtype(compute_dtype, ("fp32", "bf16x3", "bf16_approx"))
         self._warned_fallback = set()
         self.conv1 = nn.Sequential(nn.Conv2d(in_channels, channels[0], 7, stride=2, padding=3),
                                    nn.BatchNorm2d(channels[0]), nn.ReLU(), nn.MaxPool2d(2))
@@ -216,7 +216,7 @@ class CoughDetectorResidual(nn.Module):
                 blocks[i].skip = cb(p + ".skip.0", p + ".skip.1")
             stem = cb("conv1.0", "conv1.1")
             chans = (C.c_int * (nb + 1))(*self.channels)
-            dtype = _lib.DTYPES["fp32" if self.compute_dtype == "_direct" else self.compute_dtype]
+            dtype = _lib.DTYPES[self.compute_dtype]
             _lib.check(lib.cough_resnet_create_ex(C.byref(h), nb, chans, C.byref(stem), blocks, _lib.fptr(sd["fc.2.weight"]),
                                                   _lib.fptr(sd["fc.2.bias"]), float(self.conv1[1].eps), dtype),
                        "cough_resnet_create_ex")
@@ -230,7 +230,7 @@ class CoughDetectorResidual(nn.Module):
         goes through ``cough_resnet_create_ex`` onto the exact-f32 MFMA kernels, and the split-bf16 residual blocks
         are compiled for the shipped 90x101 image (block inputs 22x25 and 11x13) -- another image size runs them
         in exact f32 as well.  Results are at least as accurate as asked for; throughput is the f32 path's."""
-        if self.compute_dtype in ("fp32", "_direct"):
+        if self.compute_dtype == "fp32":
             return self.compute_dtype
         if self.channels != (32, 64, 128):
             return "fp32"
