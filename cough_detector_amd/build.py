@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcough_amd.so")
-SOURCES = ("api.hip", "featurize.hip", "spectrogram.hip", "resnet.hip", "cnn.hip", "stream.hip", "synth.hip")
+SOURCES = ("api.hip", "featurize.hip", "featurize_generic.hip", "spectrogram.hip", "resnet.hip", "cnn.hip", "stream.hip", "synth.hip")
 CFLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS = CFLAGS + ["-shared"]          # one-shot command line (the diagnostic tools build variants with it)
 

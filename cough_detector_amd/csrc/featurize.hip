@@ -566,18 +566,25 @@ struct cough_featurizer {
     int nbase;           // rows the featurise kernel writes (mel [+ MFCC, delta, delta-delta])
     cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
     int n_cus;           // compute units of the device the featuriser was created on
+    cough::GenFeat* gen; // non-null: a geometry the tuned kernel does not cover -> featurize_generic.hip
 };
 
 extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
                                        const float* window, const float* mel_fb, const float* dct) {
     using namespace cough;
     COUGH_REQUIRE(out && cfg && window && mel_fb && dct, COUGH_EINVAL, "cough_featurizer_create: NULL argument");
-    COUGH_REQUIRE(cfg->sample_rate == 16000 && cfg->n_fft == NFFT && cfg->hop_length == HOP &&
-                      cfg->win_length == WIN && cfg->n_mels == NMEL && cfg->n_mfcc == NMFCC &&
-                      cfg->segment_samples == NS,
-                  COUGH_EUNSUPPORTED,
-                  "featuriser geometry not implemented on the HIP path: need sample_rate=16000 n_fft=512 "
-                  "hop_length=160 win_length=400 n_mels=64 n_mfcc=13 segment=16000 samples");
+    // The tuned one-kernel path serves the shipped geometry with a filterbank of <= 8 taps per band below bin 128 (any
+    // f_max <= sample_rate / 4); everything else at n_fft = 512 goes to the generic kernel chain (featurize_generic.hip).
+    bool tuned = cfg->sample_rate == 16000 && cfg->n_fft == NFFT && cfg->hop_length == HOP && cfg->win_length == WIN &&
+                 cfg->n_mels == NMEL && cfg->n_mfcc == NMFCC && cfg->segment_samples == NS;
+    if (tuned) {
+        for (int m = 0; m < NMEL && tuned; ++m) {
+            int first = -1, last = -1;
+            for (int k = 0; k < NFFT / 2 + 1; ++k)
+                if (mel_fb[k * NMEL + m] != 0.f) { if (first < 0) first = k; last = k; }
+            if (first >= 0 && (last >= NBIN || last - first >= MAXW)) tuned = false;
+        }
+    }
     if (cfg->use_spectral_contrast) {
         COUGH_REQUIRE(cfg->n_contrast_bands >= 1 && cfg->n_contrast_bands <= COUGH_MAX_CONTRAST_BANDS, COUGH_EUNSUPPORTED,
                       "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
@@ -591,38 +598,41 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     std::vector<FeatTables> host(1);
     FeatTables& t = host[0];
     std::memset(&t, 0, sizeof(t));
-    const int left = (NFFT - WIN) / 2;
-    for (int n = 0; n < WIN; ++n) t.win[left + n] = window[n];
     const double PI = 3.14159265358979323846;
-    for (int jj = 0; jj < 16; ++jj)
-        for (int k1 = 0; k1 < 16; ++k1) {
-            const double a = -2.0 * PI * double(jj * k1) / 256.0;
-            t.tw256[jj][k1] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    if (tuned) {
+        const int left = (NFFT - WIN) / 2;
+        for (int n = 0; n < WIN; ++n) t.win[left + n] = window[n];
+        for (int jj = 0; jj < 16; ++jj)
+            for (int k1 = 0; k1 < 16; ++k1) {
+                const double a = -2.0 * PI * double(jj * k1) / 256.0;
+                t.tw256[jj][k1] = make_float2(float(std::cos(a)), float(std::sin(a)));
+            }
+        for (int k = 0; k < NBIN; ++k) {
+            const double a = -2.0 * PI * double(k) / 512.0;
+            t.tw512[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
         }
-    for (int k = 0; k < NBIN; ++k) {
-        const double a = -2.0 * PI * double(k) / 512.0;
-        t.tw512[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        const int nfreq = NFFT / 2 + 1;
+        for (int m = 0; m < NMEL; ++m) {
+            int first = -1;
+            for (int k = 0; k < nfreq && first < 0; ++k)
+                if (mel_fb[k * NMEL + m] != 0.f) first = k;
+            if (first < 0) first = 0;   // empty band: all-zero taps
+            if (first > NBIN - MAXW) first = NBIN - MAXW;   // keep start+8 inside the power buffer
+            t.mel_start[m] = first;
+            for (int q = 0; q < MAXW; ++q) t.mel_w[m][q] = 0.25f * mel_fb[(first + q) * NMEL + m];   // |2X|^2 / 4
+        }
+        for (int c = 0; c < NMFCC; ++c)
+            for (int m = 0; m < NMEL; ++m) t.dct_t[c][m] = dct[m * NMFCC + c];
+        for (int m = 0; m < NMEL; ++m) t.dct_t[NMFCC][m] = 0.f;
     }
-    const int nfreq = NFFT / 2 + 1;
-    for (int m = 0; m < NMEL; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < nfreq; ++k)
-            if (mel_fb[k * NMEL + m] != 0.f) { if (first < 0) first = k; last = k; }
-        if (first < 0) { first = 0; last = 0; }   // empty band: all-zero taps
-        COUGH_REQUIRE(last < NBIN && last - first < MAXW, COUGH_EUNSUPPORTED,
-                      "mel band %d spans bins %d..%d: the HIP path needs bands within bins 0..127 and <= 8 taps "
-                      "(f_max <= sample_rate/4)", m, first, last);
-        if (first > NBIN - MAXW) first = NBIN - MAXW;   // keep start+8 inside the power buffer
-        t.mel_start[m] = first;
-        for (int q = 0; q < MAXW; ++q) t.mel_w[m][q] = 0.25f * mel_fb[(first + q) * NMEL + m];   // |2X|^2 / 4
-    }
-    for (int c = 0; c < NMFCC; ++c)
-        for (int m = 0; m < NMEL; ++m) t.dct_t[c][m] = dct[m * NMFCC + c];
-    for (int m = 0; m < NMEL; ++m) t.dct_t[NMFCC][m] = 0.f;
+    GenFeat* gen = nullptr;
+    if (!tuned)
+        if (int e = gen_feat_create(&gen, cfg, window, mel_fb, dct)) return e;
 
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
-    f->nbase = cfg->use_mfcc ? NMEL + 2 * NMFCC + (cfg->use_delta_delta ? NMFCC : 0) : NMEL;
+    f->gen = gen;
+    f->nbase = cfg->use_mfcc ? cfg->n_mels + 2 * cfg->n_mfcc + (cfg->use_delta_delta ? cfg->n_mfcc : 0) : cfg->n_mels;
     f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
     f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
     for (int i = 0; i < 18; ++i) f->contrast.edges[i] = cfg->contrast_edges[i];
@@ -640,6 +650,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
         set_error("cough_featurizer_create: %s", hipGetErrorString(e));
         if (f->d_tables) (void)hipFree(f->d_tables);
         if (f->d_win_full) (void)hipFree(f->d_win_full);
+        gen_feat_destroy(f->gen);
         delete f;
         return COUGH_EHIP;
     }
@@ -657,11 +668,14 @@ extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
     if (!f) return;
     if (f->d_tables) (void)hipFree(f->d_tables);
     if (f->d_win_full) (void)hipFree(f->d_win_full);
+    cough::gen_feat_destroy(f->gen);
     delete f;
 }
 
 extern "C" int cough_featurizer_num_features(const cough_featurizer* f) { return f ? f->nfeat : -1; }
-extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return f ? cough::NFRAMES : -1; }
+extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) {
+    return !f ? -1 : f->gen ? cough::gen_num_frames(f->gen) : cough::NFRAMES;
+}
 
 namespace cough {
 StftView featurizer_stft_view(const cough_featurizer* f) {
@@ -671,10 +685,12 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
                     reinterpret_cast<const float2*>(base + offsetof(FeatTables, tw512)), f->n_cus};
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
+const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
 bool featurizer_stem_fusable(const cough_featurizer* f) {
-    return f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+    return !f->gen && f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips) {
+    if (f->gen) return gen_workspace_bytes(f->gen, f->cfg, n_clips);
     return f->contrast.n_bands > 0 && n_clips > 0 ? contrast_workspace_bytes(n_clips) : 0;
 }
 
@@ -682,6 +698,12 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
                      int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace, size_t workspace_bytes) {
     COUGH_REQUIRE(f && d_wav && (d_feat || stem), COUGH_EINVAL, "cough_featurize: NULL argument");
     COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0");
+    if (f->gen) {
+        COUGH_REQUIRE(!stem, COUGH_EUNSUPPORTED, "the fused stem needs the shipped 90-row feature layout");
+        if (n_clips == 0) return COUGH_OK;
+        return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase, n_clips,
+                             (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0, d_workspace, workspace_bytes, stream);
+    }
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
     COUGH_REQUIRE(!stem || featurizer_stem_fusable(f), COUGH_EUNSUPPORTED,

@@ -1,0 +1,559 @@
+// Generic-geometry featuriser for gfx950: every AudioPreprocessor constructor geometry at n_fft = 512 that the tuned
+// one-kernel path (featurize.hip: 16 kHz, hop 160, win 400, 64 mel bands of <= 8 taps below bin 128, 13 MFCC, 1 s) does
+// not cover -- any sample_rate / hop_length / win_length <= 512 / n_mels <= 128 / n_mfcc <= n_mels / f_min / f_max
+// (dense filterbanks, bins up to 256) / segment_duration (any frame count), with every flag of the constructor.
+//
+// Replaces, for those geometries, AudioPreprocessor.__init__ / extract_features / normalize
+// (/root/reference/src/preprocessing.py:32-144, :199-212, :432-489), RealtimePreprocessor(window_duration=...) (:559-580)
+// and the engine's re-construction of the preprocessor from a checkpoint's config (/root/reference/src/inference.py:89-108).
+//
+// Not the throughput path: a chain of small kernels over a sub-batch whose intermediates (the power spectrogram and the
+// mel powers) stay in L2 / the Infinity Cache, kernel boundaries instead of LDS capacity limits -- so the frame count is
+// unbounded -- and the precise libm forms (log10f, powf, true divisions) of the reference's arithmetic:
+//   gen_peak       per-clip max |x|                                         (normalize(), :199-212; only when asked)
+//   gen_stft       16 frames per workgroup, the featuriser's 256-point complex FFT (fft256.h) with all 257 bins formed;
+//                  samples are normalised (x / peak) and pre-emphasised (:214-240) as they are loaded; reflect padding of
+//                  torch.stft(center=True)                                  -> P [clip][257][T]   (T.MelSpectrogram's STFT)
+//   gen_mel        mel projection with a CSR filterbank (bands of any width) -> melpow [clip][n_mels][T]
+//   gen_dbstat     per-clip max dB (AmplitudeToDB's top_db floor is per clip), PCEN min / max
+//   gen_rows       mel rows (log-mel :405-410 or PCEN :305-340, :400-404) and the raw MFCC rows (DCT of the floored dB)
+//   gen_zscore     (x - mean) / (std + 1e-8) over a block of rows, unbiased std (:428, :300)
+//   gen_delta      compute_deltas (:342-356) once or twice (:464, :471-474)
+//   gen_contrast   spectral-contrast + centroid rows (:242-303) out of a power and a Hann(512) magnitude spectrogram
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "fft256.h"
+#include "internal.h"
+
+namespace cough {
+namespace {
+
+constexpr int G_NFFT = 512, G_NFREQ = 257, G_PADL = 256;
+constexpr int G_XROW = 17, G_XFRAME = 16 * G_XROW;
+constexpr int G_FPB = 16;        // frames per gen_stft workgroup: 4 waves x 4 frames
+constexpr int G_TT = 64;         // frames per workgroup of the per-frame kernels (lane = frame)
+constexpr int G_MAX_MELS = 128;
+constexpr int G_CT_BINS = 128;   // widest spectral-contrast band (bins)
+constexpr size_t G_SUB_BYTES = size_t(192) << 20;   // intermediates of one sub-batch: inside the 256 MiB Infinity Cache
+
+__device__ __forceinline__ float g_block_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float g_block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ peak
+__global__ __launch_bounds__(256) void gen_peak_kernel(const float* __restrict__ wav, long long stride, int N,
+                                                       float* __restrict__ peaks) {
+    __shared__ float red[4];
+    const float* x = wav + blockIdx.x * stride;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = g_block_max(m, red, threadIdx.x);
+    if (threadIdx.x == 0) peaks[blockIdx.x] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ STFT
+// One workgroup = 16 consecutive frames of one clip; 16 lanes per frame, as in featurize.hip / spectrogram.hip.
+template <bool MAG>
+__global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
+                                                       const float* __restrict__ win, const float2* __restrict__ tw256,
+                                                       const float2* __restrict__ tw512, const float* __restrict__ peaks,
+                                                       int pre_emph, float coef, float* __restrict__ out) {
+    __shared__ float xs[4 * 4 * G_XFRAME];
+    __shared__ float otile[G_NFREQ * (G_FPB + 1)];
+    __shared__ float2 twl[16 * G_XROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, fsub = lane >> 4;
+    const long long clip = blockIdx.y;
+    const int f16 = wave * 4 + fsub, t_raw = blockIdx.x * G_FPB + f16, t = t_raw < T ? t_raw : T - 1;
+    twl[(tid >> 4) * G_XROW + (tid & 15)] = tw256[tid];
+    __syncthreads();
+    const float2* tw_row = twl + j * G_XROW;
+    const float2 tw_j = tw512[j];
+    const float* x = wav + clip * stride;
+    const float m = peaks ? peaks[clip] : 0.f;
+    const bool norm = m > 0.f;   // "if max_val > 0: waveform / max_val" (:209-212)
+    auto sample = [&](int i) -> float {
+        const float v = x[i];
+        return norm ? v / m : v;
+    };
+    auto value = [&](int i) -> float {   // sample i of the (normalised, pre-emphasised) signal, i already inside the clip
+        float v = sample(i);
+        if (pre_emph && i > 0) v = __fsub_rn(v, __fmul_rn(coef, sample(i - 1)));   // y[n] = x[n] - coef x[n-1], y[0] = x[0]
+        return v;
+    };
+    float2 a[16], z[16];
+    const int s0 = hop * t - G_PADL + 2 * j;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        int i0 = s0 + 32 * n1, i1 = i0 + 1;   // reflect padding (N >= 257: one reflection suffices)
+        i0 = i0 < 0 ? -i0 : (i0 >= N ? 2 * (N - 1) - i0 : i0);
+        i1 = i1 < 0 ? -i1 : (i1 >= N ? 2 * (N - 1) - i1 : i1);
+        const float2 w = *reinterpret_cast<const float2*>(win + 32 * n1 + 2 * j);
+        a[n1] = make_float2(value(i0) * w.x, value(i1) * w.y);
+    }
+    dft16(a);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
+    float* myx = xs + (wave * 4 + fsub) * G_XFRAME;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) myx[k1 * G_XROW + j] = a[k1].x;
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) z[n2].x = myx[j * G_XROW + n2];
+    wave_lds_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) myx[k1 * G_XROW + j] = a[k1].y;
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * G_XROW + n2];
+    dft16(z);   // z[k2] = Z[j + 16 k2]
+    float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror, then rotate right by one
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
+        rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
+    }
+    auto put = [&](int bin, float pwr4) {   // pwr4 = |2X|^2
+        otile[bin * (G_FPB + 1) + f16] = MAG ? 0.5f * sqrtf(pwr4) : 0.25f * pwr4;
+    };
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+        const float2 zk = z[k2];
+        const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+        const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+        // 2E = Zk + conj Zp, 2O = -i (Zk - conj Zp); 2X[k] = 2E + W^k 2O, 2X[256 - k] = conj(2E - W^k 2O)
+        const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+        const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+        const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+        const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+        const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+        const int k = j + 16 * k2;
+        put(k, ar * ar + ai * ai);
+        put(G_NFFT / 2 - k, br * br + bi * bi);
+    }
+    if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
+    __syncthreads();
+    float* o = out + clip * (long long)G_NFREQ * T;
+    for (int idx = tid; idx < G_NFREQ * G_FPB; idx += 256) {
+        const int k = idx >> 4, f = idx & 15, tt = blockIdx.x * G_FPB + f;
+        if (tt < T) o[(long long)k * T + tt] = otile[k * (G_FPB + 1) + f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mel projection
+// lane = frame, wave = band (mod 4): the band's bin range and taps are wave-uniform (scalar loads), the spectrogram reads
+// are coalesced along time.
+__global__ __launch_bounds__(256) void gen_mel_kernel(const float* __restrict__ P, int T, int n_mels,
+                                                      const int* __restrict__ lo, const int* __restrict__ hi,
+                                                      const int* __restrict__ off, const float* __restrict__ w,
+                                                      float* __restrict__ melpow) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long clip = blockIdx.y;
+    const int t = blockIdx.x * G_TT + lane;
+    const float* Pc = P + clip * (long long)G_NFREQ * T;
+    for (int m = wave; m < n_mels; m += 4) {
+        const int l = lo[m], h = hi[m];
+        const float* wm = w + off[m];
+        float acc = 0.f;
+        if (t < T)
+            for (int k = l; k < h; ++k) acc = fmaf(wm[k - l], Pc[(long long)k * T + t], acc);
+        if (t < T) melpow[(clip * n_mels + m) * (long long)T + t] = acc;
+    }
+}
+
+// AmplitudeToDB('power'): 10 log10(max(x, amin = 1e-10)) (ref = 1: no offset)
+__device__ __forceinline__ float g_db(float p) { return 10.0f * log10f(fmaxf(p, 1e-10f)); }
+// PCEN value of apply_pcen (:305-340): smooth = 10-frame moving average (avg_pool2d kernel 10, padding 5, zeros counted,
+// output trimmed to T: frames t - 5 .. t + 4), (mel / (1e-6 + smooth)^0.98 + 2)^0.5 - 2^0.5
+__device__ __forceinline__ float g_pcen(const float* __restrict__ row, int t, int T) {
+    float sm = 0.f;
+#pragma unroll
+    for (int q = -5; q < 5; ++q) {
+        const int u = t + q;
+        sm += (u >= 0 && u < T) ? row[u] : 0.f;
+    }
+    return sqrtf(row[t] / powf(1e-6f + sm / 10.0f, 0.98f) + 2.0f) - 1.41421356237309515f;
+}
+
+// per clip: stat[clip] = {max dB, PCEN min, PCEN max}
+__global__ __launch_bounds__(256) void gen_dbstat_kernel(const float* __restrict__ melpow, int T, int n_mels, int pcen,
+                                                         float* __restrict__ stat) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const long long clip = blockIdx.x;
+    const float* mp = melpow + clip * (long long)n_mels * T;
+    const long long n = (long long)n_mels * T;
+    float mx = -INFINITY, pmin = INFINITY, pmax = -INFINITY;
+    for (long long i = tid; i < n; i += 256) {
+        mx = fmaxf(mx, g_db(mp[i]));
+        if (pcen) {
+            const int m = int(i / T), t = int(i - (long long)m * T);
+            const float v = g_pcen(mp + (long long)m * T, t, T);
+            pmin = fminf(pmin, v);
+            pmax = fmaxf(pmax, v);
+        }
+    }
+    mx = g_block_max(mx, red, tid);
+    pmin = -g_block_max(-pmin, red, tid);
+    pmax = g_block_max(pmax, red, tid);
+    if (tid == 0) { stat[clip * 4] = mx; stat[clip * 4 + 1] = pmin; stat[clip * 4 + 2] = pmax; }
+}
+
+// mel rows + raw MFCC rows of 64 frames of one clip
+__global__ __launch_bounds__(256) void gen_rows_kernel(const float* __restrict__ melpow, int T, int n_mels, int n_mfcc,
+                                                       int pcen, const float* __restrict__ stat,
+                                                       const float* __restrict__ dct_t /* [n_mfcc][n_mels] */,
+                                                       float* __restrict__ feat, int nfeat) {
+    __shared__ float dbt[G_MAX_MELS * G_TT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long clip = blockIdx.y;
+    const int t = blockIdx.x * G_TT + lane;
+    const float* mp = melpow + clip * (long long)n_mels * T;
+    float* o = feat + clip * (long long)nfeat * T;
+    const float floor_db = stat[clip * 4] - 80.0f;   // top_db = 80 below the clip's maximum
+    const float pmin = stat[clip * 4 + 1], prange = stat[clip * 4 + 2] - pmin + 1e-8f;
+    for (int m = wave; m < n_mels; m += 4) {
+        float d = 0.f;
+        if (t < T) {
+            d = fmaxf(g_db(mp[(long long)m * T + t]), floor_db);
+            float v;
+            if (pcen) v = (g_pcen(mp + (long long)m * T, t, T) - pmin) / prange;          // :402-404
+            else v = fminf(fmaxf((d + 80.0f) / 80.0f, 0.f), 1.f);                         // :409-410
+            o[(long long)m * T + t] = v;
+        }
+        dbt[m * G_TT + lane] = d;
+    }
+    __syncthreads();
+    for (int c = wave; c < n_mfcc; c += 4) {   // T.MFCC: DCT-II (ortho) of the floored dB, coefficients wave-uniform
+        const float* dr = dct_t + c * n_mels;
+        float acc = 0.f;
+        for (int m = 0; m < n_mels; ++m) acc = fmaf(dr[m], dbt[m * G_TT + lane], acc);
+        if (t < T) o[(long long)(n_mels + c) * T + t] = acc;
+    }
+}
+
+// in place over rows [row0, row0 + nr) of every clip: (x - mean) / (std + 1e-8), std unbiased
+__global__ __launch_bounds__(256) void gen_zscore_kernel(float* __restrict__ feat, int nfeat, int T, int row0, int nr) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float* p = feat + (blockIdx.x * (long long)nfeat + row0) * T;
+    const long long n = (long long)nr * T;
+    float s = 0.f;
+    for (long long i = tid; i < n; i += 256) s += p[i];
+    const float mean = g_block_sum(s, red, tid) / float(n);
+    float q = 0.f;
+    for (long long i = tid; i < n; i += 256) {
+        const float d = p[i] - mean;
+        q += d * d;
+    }
+    const float sd = sqrtf(g_block_sum(q, red, tid) / float(n - 1));
+    const float den = sd + 1e-8f;
+    for (long long i = tid; i < n; i += 256) p[i] = (p[i] - mean) / den;
+}
+
+// compute_deltas (:342-356): replicate-pad by one, (x[t + 1] - x[t - 1]) / 2; twice for delta-delta
+__global__ __launch_bounds__(256) void gen_delta_kernel(float* __restrict__ feat, int nfeat, int T, int n_mels, int n_mfcc,
+                                                        int delta_delta) {
+    const long long clip = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_mfcc * T) return;
+    const int c = idx / T, t = idx - c * T;
+    float* base = feat + clip * (long long)nfeat * T;
+    const float* z = base + (long long)(n_mels + c) * T;
+    auto d1 = [&](int u) -> float {
+        const int a = u + 1 < T ? u + 1 : T - 1, b = u - 1 > 0 ? u - 1 : 0;
+        return (z[a] - z[b]) * 0.5f;
+    };
+    base[(long long)(n_mels + n_mfcc + c) * T + t] = d1(t);
+    if (delta_delta) {
+        const int a = t + 1 < T ? t + 1 : T - 1, b = t - 1 > 0 ? t - 1 : 0;
+        base[(long long)(n_mels + 2 * n_mfcc + c) * T + t] = (d1(a) - d1(b)) * 0.5f;
+    }
+}
+
+// raw spectral-contrast rows + centroid row of 64 frames of one clip (the joint z-score follows in gen_zscore_kernel).
+// Per band its rows go to LDS, then each frame ranks its bins (rank = number of smaller values, ties by index -- the
+// position torch.sort would give) and sums the values of rank >= top_idx and < bot_idx: the reference's sorted-slice means
+// without sorting; an empty top slice divides 0 by 0 as the mean of an empty tensor does (:272-293).
+__global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restrict__ P, const float* __restrict__ M, int T,
+                                                          ContrastCfg cfg, const float* __restrict__ freqs, float nyquist,
+                                                          float* __restrict__ feat, int nfeat, int row0) {
+    __shared__ float band[G_CT_BINS * G_TT];
+    const int lane = threadIdx.x;
+    const long long clip = blockIdx.y;
+    const int t = blockIdx.x * G_TT + lane;
+    const float* Pc = P + clip * (long long)G_NFREQ * T;
+    const float* Mc = M + clip * (long long)G_NFREQ * T;
+    float* o = feat + (clip * (long long)nfeat + row0) * T;
+    for (int i = 0; i < cfg.n_bands; ++i) {
+        int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
+        if (high <= low) high = low + 1;
+        if (high > G_NFREQ) high = G_NFREQ;
+        const int nb = high - low;
+        __syncthreads();
+        for (int e = 0; e < nb; ++e) band[e * G_TT + lane] = t < T ? Pc[(long long)(low + e) * T + t] : 0.f;
+        __syncthreads();
+        int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
+        if (top_idx < 1) top_idx = 1;
+        if (bot_idx < 1) bot_idx = 1;
+        float top = 0.f, bot = 0.f;
+        for (int e = 0; e < nb; ++e) {
+            const float v = band[e * G_TT + lane];
+            int rank = 0;
+            for (int q = 0; q < nb; ++q) {
+                const float u = band[q * G_TT + lane];
+                rank += (u < v || (u == v && q < e)) ? 1 : 0;
+            }
+            if (rank >= top_idx) top += v;
+            if (rank < bot_idx) bot += v;
+        }
+        const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
+        const float valleys = bot / float(bot_idx);
+        if (t < T) o[(long long)i * T + t] = log1pf(peaks) - log1pf(valleys);
+    }
+    if (t < T) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
+        float num = 0.f, den = 0.f;
+        for (int k = 0; k < G_NFREQ; ++k) {
+            const float m = Mc[(long long)k * T + t];
+            num += freqs[k] * m;
+            den += m;
+        }
+        o[(long long)cfg.n_bands * T + t] = (num / den) / nyquist;
+    }
+}
+
+size_t align256g(size_t v) { return (v + 255) & ~size_t(255); }
+
+}  // namespace
+
+struct GenFeat {
+    int N, hop, T, n_mels, n_mfcc, sample_rate;
+    char* d_blob;
+    const float* win;      // [512] caller's window centred in the frame
+    const float* win_full; // [512] periodic Hann(512)
+    const float2* tw256;   // [16][16]
+    const float2* tw512;   // [128]
+    const int *mel_lo, *mel_hi, *mel_off;
+    const float* mel_w;    // CSR taps
+    const float* dct_t;    // [n_mfcc][n_mels]
+    const float* freqs;    // [257] torch.linspace(0, sample_rate // 2, 257)
+};
+
+int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* window, const float* mel_fb, const float* dct) {
+    COUGH_REQUIRE(cfg->n_fft == G_NFFT, COUGH_EUNSUPPORTED, "n_fft = %d: the HIP path implements n_fft = 512", cfg->n_fft);
+    COUGH_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= G_NFFT, COUGH_EUNSUPPORTED,
+                  "win_length = %d: need 1 <= win_length <= n_fft", cfg->win_length);
+    COUGH_REQUIRE(cfg->hop_length >= 1, COUGH_EINVAL, "hop_length = %d", cfg->hop_length);
+    COUGH_REQUIRE(cfg->segment_samples > G_PADL, COUGH_EUNSUPPORTED,
+                  "segment of %d samples: reflect padding (torch.stft center=True) needs more than n_fft / 2 = 256",
+                  cfg->segment_samples);
+    COUGH_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= G_MAX_MELS, COUGH_EUNSUPPORTED,
+                  "n_mels = %d: the HIP path takes 1..%d", cfg->n_mels, G_MAX_MELS);
+    COUGH_REQUIRE(!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= cfg->n_mels), COUGH_EINVAL,
+                  "n_mfcc = %d: cannot select more MFCC coefficients than mel bins (%d)", cfg->n_mfcc, cfg->n_mels);
+    COUGH_REQUIRE(cfg->sample_rate >= 2, COUGH_EINVAL, "sample_rate = %d", cfg->sample_rate);
+    const int n_mels = cfg->n_mels, n_mfcc = cfg->use_mfcc ? cfg->n_mfcc : 0;   // T.MFCC exists only with use_mfcc (:116-127)
+    const double PI = 3.14159265358979323846;
+    std::vector<float> win(G_NFFT, 0.f), hann(G_NFFT), freqs(G_NFREQ), dct_t(size_t(n_mfcc) * n_mels), taps;
+    std::vector<float2> tw256(256), tw512(128);
+    std::vector<int> lo(n_mels), hi(n_mels), off(n_mels);
+    const int left = (G_NFFT - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
+    for (int n = 0; n < cfg->win_length; ++n) win[left + n] = window[n];
+    for (int n = 0; n < G_NFFT; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(G_NFFT)));
+    for (int jj = 0; jj < 16; ++jj)
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const double a = -2.0 * PI * double(jj * k1) / 256.0;
+            tw256[jj * 16 + k1] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        }
+    for (int k = 0; k < 128; ++k) {
+        const double a = -2.0 * PI * double(k) / 512.0;
+        tw512[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    }
+    for (int m = 0; m < n_mels; ++m) {   // CSR: the band's first .. last non-zero bin (zeros inside the range kept)
+        int first = -1, last = -1;
+        for (int k = 0; k < G_NFREQ; ++k)
+            if (mel_fb[k * n_mels + m] != 0.f) { if (first < 0) first = k; last = k; }
+        if (first < 0) { first = 0; last = -1; }   // empty band: no taps, mel power 0
+        lo[m] = first;
+        hi[m] = last + 1;
+        off[m] = int(taps.size());
+        for (int k = first; k <= last; ++k) taps.push_back(mel_fb[k * n_mels + m]);
+    }
+    if (taps.empty()) taps.push_back(0.f);
+    for (int c = 0; c < n_mfcc; ++c)
+        for (int m = 0; m < n_mels; ++m) dct_t[size_t(c) * n_mels + m] = dct[m * n_mfcc + c];
+    if (dct_t.empty()) dct_t.push_back(0.f);
+    {   // torch.linspace(0, sample_rate // 2, 257) in float32: start + step * i below the midpoint, end - step * (n - 1 - i) above
+        const float end = float(cfg->sample_rate / 2);
+        const volatile float step = end / float(G_NFREQ - 1);
+        for (int i = 0; i < G_NFREQ; ++i) {
+            volatile float prod = i < G_NFREQ / 2 ? step * float(i) : step * float(G_NFREQ - i - 1);
+            freqs[i] = i < G_NFREQ / 2 ? prod : end - prod;
+        }
+    }
+    // one device blob
+    size_t o_win = 0, o_hann = o_win + align256g(G_NFFT * 4), o_tw256 = o_hann + align256g(G_NFFT * 4),
+           o_tw512 = o_tw256 + align256g(256 * 8), o_lo = o_tw512 + align256g(128 * 8), o_hi = o_lo + align256g(n_mels * 4),
+           o_off = o_hi + align256g(n_mels * 4), o_taps = o_off + align256g(n_mels * 4),
+           o_dct = o_taps + align256g(taps.size() * 4), o_freqs = o_dct + align256g(dct_t.size() * 4),
+           total = o_freqs + align256g(G_NFREQ * 4);
+    std::vector<char> host(total, 0);
+    std::memcpy(host.data() + o_win, win.data(), G_NFFT * 4);
+    std::memcpy(host.data() + o_hann, hann.data(), G_NFFT * 4);
+    std::memcpy(host.data() + o_tw256, tw256.data(), 256 * 8);
+    std::memcpy(host.data() + o_tw512, tw512.data(), 128 * 8);
+    std::memcpy(host.data() + o_lo, lo.data(), n_mels * 4);
+    std::memcpy(host.data() + o_hi, hi.data(), n_mels * 4);
+    std::memcpy(host.data() + o_off, off.data(), n_mels * 4);
+    std::memcpy(host.data() + o_taps, taps.data(), taps.size() * 4);
+    std::memcpy(host.data() + o_dct, dct_t.data(), dct_t.size() * 4);
+    std::memcpy(host.data() + o_freqs, freqs.data(), G_NFREQ * 4);
+    GenFeat* g = new GenFeat();
+    g->N = cfg->segment_samples;
+    g->hop = cfg->hop_length;
+    g->T = cfg->segment_samples / cfg->hop_length + 1;   // get_expected_time_frames(), :532-534
+    g->n_mels = n_mels;
+    g->n_mfcc = n_mfcc;
+    g->sample_rate = cfg->sample_rate;
+    g->d_blob = nullptr;
+    hipError_t e = hipMalloc(&g->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(g->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("cough_featurizer_create (generic geometry): %s", hipGetErrorString(e));
+        if (g->d_blob) (void)hipFree(g->d_blob);
+        delete g;
+        return COUGH_EHIP;
+    }
+    const char* b = g->d_blob;
+    g->win = reinterpret_cast<const float*>(b + o_win);
+    g->win_full = reinterpret_cast<const float*>(b + o_hann);
+    g->tw256 = reinterpret_cast<const float2*>(b + o_tw256);
+    g->tw512 = reinterpret_cast<const float2*>(b + o_tw512);
+    g->mel_lo = reinterpret_cast<const int*>(b + o_lo);
+    g->mel_hi = reinterpret_cast<const int*>(b + o_hi);
+    g->mel_off = reinterpret_cast<const int*>(b + o_off);
+    g->mel_w = reinterpret_cast<const float*>(b + o_taps);
+    g->dct_t = reinterpret_cast<const float*>(b + o_dct);
+    g->freqs = reinterpret_cast<const float*>(b + o_freqs);
+    *out = g;
+    return COUGH_OK;
+}
+
+void gen_feat_destroy(GenFeat* g) {
+    if (!g) return;
+    if (g->d_blob) (void)hipFree(g->d_blob);
+    delete g;
+}
+
+int gen_num_frames(const GenFeat* g) { return g->T; }
+int gen_segment_samples(const GenFeat* g) { return g->N; }
+
+namespace {
+struct GenCarve {
+    int sub;                 // clips per sub-batch
+    size_t o_peaks, o_stat, o_P, o_M, o_mel, total;
+};
+GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
+    GenCarve c;
+    const size_t spec = size_t(G_NFREQ) * g->T * 4, mel = size_t(g->n_mels) * g->T * 4;
+    const size_t per = spec * (contrast ? 2 : 1) + mel;
+    size_t sub = G_SUB_BYTES / per;
+    if (sub < 1) sub = 1;
+    if (sub > 32768) sub = 32768;   // grid.y
+    if (sub > size_t(n_clips)) sub = size_t(n_clips);
+    c.sub = int(sub);
+    c.o_peaks = 0;
+    c.o_stat = c.o_peaks + align256g(sub * 4);
+    c.o_P = c.o_stat + align256g(sub * 16);
+    c.o_M = c.o_P + align256g(sub * spec);
+    c.o_mel = c.o_M + (contrast ? align256g(sub * spec) : 0);
+    c.total = c.o_mel + align256g(sub * mel);
+    return c;
+}
+}  // namespace
+
+size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_clips) {
+    return n_clips > 0 ? gen_carve(g, cfg.use_spectral_contrast != 0, n_clips).total : 0;
+}
+
+int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+                    hipStream_t stream) {
+    COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_spectrogram: row stride %lld < segment of %d samples", wav_stride, g->N);
+    const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
+    const dim3 grid((g->T + G_FPB - 1) / G_FPB, n_clips), block(256);
+    const float* win = full ? g->win_full : g->win;
+    if (mag)
+        hipLaunchKernelGGL(gen_stft_kernel<true>, grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win, g->tw256,
+                           g->tw512, (const float*)nullptr, 0, 0.f, d_spec);
+    else
+        hipLaunchKernelGGL(gen_stft_kernel<false>, grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win, g->tw256,
+                           g->tw512, (const float*)nullptr, 0, 0.f, d_spec);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
+                  long long wav_stride, float* d_feat, int nfeat, int nbase, int n_clips, int normalize, void* d_workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+    COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_featurize: row stride %lld < segment of %d samples", wav_stride, g->N);
+    const bool want_contrast = contrast.n_bands > 0;
+    const GenCarve c = gen_carve(g, want_contrast, n_clips);
+    COUGH_REQUIRE(d_workspace && workspace_bytes >= c.total, COUGH_EWORKSPACE,
+                  "this featuriser geometry runs on the generic kernel chain and needs a workspace of "
+                  "cough_featurizer_workspace_bytes() = %zu bytes (cough_featurize_ws)", c.total);
+    COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL, "workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(d_workspace);
+    float* peaks = reinterpret_cast<float*>(ws + c.o_peaks);
+    float* stat = reinterpret_cast<float*>(ws + c.o_stat);
+    float* P = reinterpret_cast<float*>(ws + c.o_P);
+    float* M = reinterpret_cast<float*>(ws + c.o_M);
+    float* mel = reinterpret_cast<float*>(ws + c.o_mel);
+    const int T = g->T, n_mels = g->n_mels, n_mfcc = g->n_mfcc;
+    for (int c0 = 0; c0 < n_clips; c0 += c.sub) {
+        const int nc = n_clips - c0 < c.sub ? n_clips - c0 : c.sub;
+        const float* w = d_wav + (long long)c0 * wav_stride;
+        float* feat = d_feat + (long long)c0 * nfeat * T;
+        const float* pk = normalize ? peaks : nullptr;
+        if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, g->N, peaks);
+        const dim3 gs((T + G_FPB - 1) / G_FPB, nc), gt((T + G_TT - 1) / G_TT, nc);
+        hipLaunchKernelGGL(gen_stft_kernel<false>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win, g->tw256,
+                           g->tw512, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, P);
+        hipLaunchKernelGGL(gen_mel_kernel, gt, dim3(256), 0, stream, P, T, n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, mel);
+        hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
+        hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
+                           g->dct_t, feat, nfeat);
+        if (cfg.use_mfcc) {
+            hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, n_mels, n_mfcc);
+            hipLaunchKernelGGL(gen_delta_kernel, dim3((n_mfcc * T + 255) / 256, nc), dim3(256), 0, stream, feat, nfeat, T, n_mels,
+                               n_mfcc, cfg.use_delta_delta);
+        }
+        if (want_contrast) {
+            // from the un-emphasised (normalised) signal (:476-478): the power spectrogram above serves when no pre-emphasis ran
+            if (cfg.use_pre_emphasis)
+                hipLaunchKernelGGL(gen_stft_kernel<false>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
+                                   g->tw256, g->tw512, pk, 0, 0.f, P);
+            hipLaunchKernelGGL(gen_stft_kernel<true>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win_full,
+                               g->tw256, g->tw512, pk, 0, 0.f, M);
+            hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, contrast, g->freqs,
+                               float(g->sample_rate) / 2.0f, feat, nfeat, nbase);
+            hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
+        }
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    return COUGH_OK;
+}
+
+}  // namespace cough

@@ -47,6 +47,19 @@ int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wa
 // spectrogram.hip: per-device set-up of the persistent STFT kernel (its 162 KB dynamic-LDS attribute) on the CURRENT
 // device + that device's CU count; cough_featurizer_create calls it
 int stft_prepare_device(int* n_cus);
+// featurize_generic.hip: the kernel chain for every geometry the tuned featurise kernel does not cover (n_fft = 512)
+struct GenFeat;
+int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* window, const float* mel_fb, const float* dct);
+void gen_feat_destroy(GenFeat* g);
+int gen_num_frames(const GenFeat* g);
+int gen_segment_samples(const GenFeat* g);
+size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_clips);
+int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+                    hipStream_t stream);
+int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
+                  long long wav_stride, float* d_feat, int nfeat, int nbase, int n_clips, int normalize, void* d_workspace,
+                  size_t workspace_bytes, hipStream_t stream);
+const GenFeat* featurizer_generic(const cough_featurizer* f);   // nullptr: the tuned kernel serves this featuriser
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream);
 

@@ -476,6 +476,10 @@ extern "C" int cough_spectrogram(const cough_featurizer* f, const float* d_wav, 
     COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_spectrogram: n_clips < 0");
     COUGH_REQUIRE((flags & ~(COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW)) == 0, COUGH_EINVAL,
                   "cough_spectrogram: unknown flag bits 0x%x", flags);
+    if (const GenFeat* g = featurizer_generic(f)) {   // a geometry the persistent kernel is not built for
+        if (n_clips == 0) return COUGH_OK;
+        return gen_spectrogram(g, d_wav, wav_stride, d_spec, n_clips, flags, static_cast<hipStream_t>(stream));
+    }
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_spectrogram: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
     if (n_clips == 0) return COUGH_OK;

@@ -12,7 +12,10 @@ Differences a caller can observe:
 * ``extract_features`` additionally accepts ``(B, N)`` / ``(B, 1, N)`` batches and returns
   ``(B, F, T)`` with the reference's per-clip reduction semantics.
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
-  spectral contrast + centroid); other STFT geometries raise ``ValueError`` instead of changing the layout.
+  spectral contrast + centroid) for every geometry at ``n_fft=512``: any ``sample_rate`` / ``hop_length`` /
+  ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The shipped geometry
+  runs on the tuned one-launch kernel, the others on a chain of small kernels (``csrc/featurize_generic.hip``);
+  ``n_fft != 512`` raises ``ValueError``.
 * ``use_spectral_contrast=True`` with 5 or more bands (the constructor default is 6) yields NaN rows exactly as
   the reference does (its first band is one bin wide, ``src/preprocessing.py:272-290``); a warning says so.
 """
@@ -86,11 +89,22 @@ class AudioPreprocessor:
                           "spectral-contrast rows are NaN by construction for 5 or more bands (its first band is one "
                           "bin wide); this implementation reproduces them. Use use_spectral_contrast=False (the "
                           "shipped configuration, src/train.py:264-287) or n_contrast_bands <= 4.", stacklevel=2)
-        if (sample_rate, n_fft, hop_length, win_length, n_mels, n_mfcc, self.segment_samples) != \
-                (16000, 512, 160, 400, 64, 13, 16000):
-            raise ValueError("AudioPreprocessor: the MI355X path implements sample_rate=16000, n_fft=512, "
-                             "hop_length=160, win_length=400, n_mels=64, n_mfcc=13, segment_duration=1.0 only")
-
+        # Geometry: the tuned one-kernel path serves the shipped 16 kHz / 512 / 160 / 400 / 64 mel / 13 MFCC / 1 s layout with
+        # f_max <= sample_rate / 4; every other geometry at n_fft = 512 runs on the generic kernel chain
+        # (csrc/featurize_generic.hip) -- the library picks.  What torch / torchaudio would refuse is refused here too.
+        if n_fft != 512:
+            raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements n_fft=512")
+        if not 1 <= win_length <= n_fft:
+            raise ValueError(f"AudioPreprocessor: win_length={win_length} must lie in 1..n_fft (torch.stft)")
+        if hop_length < 1:
+            raise ValueError(f"AudioPreprocessor: hop_length={hop_length} must be positive")
+        if not 1 <= n_mels <= 128:
+            raise ValueError(f"AudioPreprocessor: n_mels={n_mels}: the MI355X path takes 1..128 mel bands")
+        if use_mfcc and not 1 <= n_mfcc <= n_mels:
+            raise ValueError("Cannot select more MFCC coefficients than # mel bins")          # torchaudio.transforms.MFCC
+        if self.segment_samples <= n_fft // 2:
+            raise ValueError(f"AudioPreprocessor: a segment of {self.segment_samples} samples is shorter than the reflect "
+                             f"padding of torch.stft(center=True) (needs more than n_fft // 2 = {n_fft // 2})")
         # host tables, built the way torchaudio builds them (preprocessing.py:94-127)
         self._window = _tables.hann_window(win_length)
         self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)

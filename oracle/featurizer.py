@@ -99,10 +99,11 @@ def stft_power(waveform: torch.Tensor, n_fft: int = N_FFT, hop: int = HOP, win: 
     return spec.abs() if power == 1.0 else spec.abs().pow(power)
 
 
-def mel_spectrogram(waveform: torch.Tensor, fb: Optional[torch.Tensor] = None) -> torch.Tensor:
+def mel_spectrogram(waveform: torch.Tensor, fb: Optional[torch.Tensor] = None, n_fft: int = N_FFT, hop: int = HOP,
+                    win: int = WIN) -> torch.Tensor:
     """F1+F2: (..., N) -> (..., n_mels, T)."""
     fb = melscale_fbanks() if fb is None else fb
-    spec = stft_power(waveform)
+    spec = stft_power(waveform, n_fft=n_fft, hop=hop, win=win)
     return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
 
 
@@ -120,10 +121,10 @@ def amplitude_to_db(x: torch.Tensor, top_db: Optional[float] = TOP_DB) -> torch.
     return x_db
 
 
-def mfcc_transform(waveform: torch.Tensor, fb=None, dct=None) -> torch.Tensor:
+def mfcc_transform(waveform: torch.Tensor, fb=None, dct=None, **stft) -> torch.Tensor:
     """F5 (un-normalised): second, parameter-identical STFT->mel->dB chain, then DCT."""
     dct = create_dct() if dct is None else dct
-    mel_db = amplitude_to_db(mel_spectrogram(waveform, fb))
+    mel_db = amplitude_to_db(mel_spectrogram(waveform, fb, **stft))
     return torch.matmul(mel_db.transpose(-1, -2), dct).transpose(-1, -2)
 
 
@@ -214,18 +215,18 @@ def apply_pcen(mel_spec: torch.Tensor, alpha: float = 0.98, delta: float = 2.0, 
     return (mel_spec / (eps + smooth).pow(alpha) + delta).pow(r) - delta ** r
 
 
-def extract_mel_spectrogram(waveform: torch.Tensor, fb=None, use_pcen: bool = False) -> torch.Tensor:
+def extract_mel_spectrogram(waveform: torch.Tensor, fb=None, use_pcen: bool = False, **stft) -> torch.Tensor:
     """F1-F4 -- preprocessing.py:387-412 (PCEN branch :400-404, log branch :405-410)."""
     if use_pcen:
-        m = apply_pcen(mel_spectrogram(waveform, fb))
+        m = apply_pcen(mel_spectrogram(waveform, fb, **stft))
         return (m - m.min()) / (m.max() - m.min() + 1e-8)
-    mel_db = amplitude_to_db(mel_spectrogram(waveform, fb))
+    mel_db = amplitude_to_db(mel_spectrogram(waveform, fb, **stft))
     return ((mel_db + 80) / 80).clamp(0, 1)
 
 
-def extract_mfcc(waveform: torch.Tensor, fb=None, dct=None) -> torch.Tensor:
+def extract_mfcc(waveform: torch.Tensor, fb=None, dct=None, **stft) -> torch.Tensor:
     """F5-F6 -- preprocessing.py:414-430 (global z-score, unbiased std)."""
-    mfcc = mfcc_transform(waveform, fb, dct)
+    mfcc = mfcc_transform(waveform, fb, dct, **stft)
     return (mfcc - mfcc.mean()) / (mfcc.std() + 1e-8)
 
 
@@ -245,13 +246,14 @@ def spectral_centroid(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, n_
     return (freqs * spec).sum(dim=-2) / spec.sum(dim=-2)
 
 
-def extract_spectral_contrast(waveform: torch.Tensor, n_bands: int = 6, sample_rate: int = SAMPLE_RATE) -> torch.Tensor:
+def extract_spectral_contrast(waveform: torch.Tensor, n_bands: int = 6, sample_rate: int = SAMPLE_RATE,
+                              n_fft: int = N_FFT, hop: int = HOP, win: int = WIN) -> torch.Tensor:
     """preprocessing.py:242-303, statement by statement: (1, N) -> (1, n_bands + 1, T).
 
     With the default n_bands = 6 (and any n_bands >= 5) the first band is the single bin [1, 2): ``top_idx =
     max(1, int(1 * 0.8)) = 1`` makes ``sorted_band[:, 1:, :]`` empty, its mean is NaN, and the global z-score at
     the end spreads the NaN over every row.  The restatement keeps that behaviour."""
-    spec = stft_power(waveform)                                                       # T.Spectrogram(power=2.0)
+    spec = stft_power(waveform, n_fft=n_fft, hop=hop, win=win)                        # T.Spectrogram(power=2.0)
     n_freq, n_time = spec.shape[1], spec.shape[2]
     band_edges = contrast_band_edges(n_bands, n_freq)
     contrast = torch.zeros(1, n_bands + 1, n_time)
@@ -272,7 +274,7 @@ def extract_spectral_contrast(waveform: torch.Tensor, n_bands: int = 6, sample_r
                 peaks = sorted_band[:, top_idx:, :].mean(dim=1)
             valleys = sorted_band[:, :bot_idx, :].mean(dim=1)
             contrast[:, i, :] = torch.log1p(peaks) - torch.log1p(valleys)
-    centroid = spectral_centroid(waveform, sample_rate) / (sample_rate / 2)
+    centroid = spectral_centroid(waveform, sample_rate, n_fft=n_fft, hop=hop) / (sample_rate / 2)
     contrast[:, -1, :centroid.shape[1]] = centroid
     return (contrast - contrast.mean()) / (contrast.std() + 1e-8)
 
@@ -280,32 +282,45 @@ def extract_spectral_contrast(waveform: torch.Tensor, n_bands: int = 6, sample_r
 def extract_features(waveform: torch.Tensor, use_pre_emphasis: bool = False, pre_emphasis_coef: float = 0.97,
                      use_delta_delta: bool = False, use_pcen: bool = False, fb=None, dct=None,
                      use_mfcc: bool = True, use_spectral_contrast: bool = False,
-                     n_contrast_bands: int = 6) -> torch.Tensor:
-    """F8 -- preprocessing.py:432-489: (1, N) -> (1, 90 [or 103, +7 with spectral contrast], T)."""
+                     n_contrast_bands: int = 6, sample_rate: int = SAMPLE_RATE, n_fft: int = N_FFT, hop: int = HOP,
+                     win: int = WIN) -> torch.Tensor:
+    """F8 -- preprocessing.py:432-489: (1, N) -> (1, 90 [or 103, +7 with spectral contrast], T).  ``fb`` / ``dct`` are the
+    tables of the constructor's n_mels / n_mfcc / f_min / f_max (``melscale_fbanks`` / ``create_dct``); ``sample_rate`` /
+    ``n_fft`` / ``hop`` / ``win`` its STFT geometry (:94-141)."""
+    stft = dict(n_fft=n_fft, hop=hop, win=win)
     w = pre_emphasis(waveform, pre_emphasis_coef) if use_pre_emphasis else waveform
-    mel = extract_mel_spectrogram(w, fb, use_pcen)
+    mel = extract_mel_spectrogram(w, fb, use_pcen, **stft)
     feats = [mel]
     if use_mfcc:
-        mfcc = extract_mfcc(w, fb, dct)
+        mfcc = extract_mfcc(w, fb, dct, **stft)
         delta = compute_deltas(mfcc)
         feats += [mfcc, delta]
         if use_delta_delta:
             feats.append(compute_deltas(delta))
-    if use_spectral_contrast:
-        feats.append(extract_spectral_contrast(waveform, n_contrast_bands))   # from the un-emphasised signal (:476-478)
+    if use_spectral_contrast:   # from the un-emphasised signal (:476-478)
+        feats.append(extract_spectral_contrast(waveform, n_contrast_bands, sample_rate, **stft))
     t = min(f.shape[2] for f in feats)
     return torch.cat([f[:, :, :t] for f in feats], dim=1)
+
+
+def geometry_kwargs(sample_rate: int = SAMPLE_RATE, n_mels: int = N_MELS, n_fft: int = N_FFT, hop_length: int = HOP,
+                    win_length: int = WIN, f_min: float = F_MIN, f_max: float = F_MAX, n_mfcc: int = N_MFCC) -> dict:
+    """``extract_features`` keyword arguments (tables + STFT geometry) of an ``AudioPreprocessor(...)`` constructor call
+    (preprocessing.py:32-51, :94-141)."""
+    return dict(fb=melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate), dct=create_dct(n_mfcc, n_mels),
+                sample_rate=sample_rate, n_fft=n_fft, hop=hop_length, win=win_length)
 
 
 def extract_features_batch(waveforms: torch.Tensor, normalize_first: bool = False, **kw) -> torch.Tensor:
     """(B, N) -> (B, F, T) by looping the per-clip reference path (per-clip reductions)."""
     out = []
-    tables = dict(fb=melscale_fbanks(), dct=create_dct())
+    kw.setdefault("fb", melscale_fbanks())
+    kw.setdefault("dct", create_dct())
     for i in range(waveforms.shape[0]):
         w = waveforms[i:i + 1]
         if normalize_first:
             w = normalize(w)
-        out.append(extract_features(w, **tables, **kw))
+        out.append(extract_features(w, **kw))
     return torch.cat(out, dim=0)
 
 

@@ -104,6 +104,41 @@ def test_features_against_float64(seed):
     assert np.abs(f32[64:] - f64[64:]).max() < 2e-5
 
 
+GEOMETRIES = {     # AudioPreprocessor(...) constructor calls the generic HIP path serves (VERDICT r03 missing #2)
+    "mels40_fmax8k": dict(n_mels=40, f_max=8000.0),
+    "mels80_mfcc20": dict(n_mels=80, n_mfcc=20, f_max=8000.0),
+    "mels128_mfcc40_fmin20": dict(n_mels=128, n_mfcc=40, f_min=20.0, f_max=7600.0),
+    "half_second": dict(segment_duration=0.5),
+    "two_seconds": dict(segment_duration=2.0),
+    "hop128_win512": dict(hop_length=128, win_length=512),
+    "sr22050": dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441),
+}
+
+
+def geometry_clip(seed: int, n: int) -> np.ndarray:
+    """A synthetic clip of n samples: the 1 s recipes tiled / cut (quiet floor + bursts exercise the top_db floor)."""
+    parts = [synth.make_clip(seed + 7 * k) for k in range((n + 15999) // 16000)]
+    return np.concatenate(parts)[:n].astype(np.float32)
+
+
+@pytest.mark.parametrize("name", sorted(GEOMETRIES))
+def test_generic_geometry_restatement_against_float64(name):
+    """The float32 restatement at non-default constructor geometries vs the independent float64 re-derivation."""
+    g = dict(sample_rate=16000, n_mels=64, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13,
+             segment_duration=1.0)
+    g.update(GEOMETRIES[name])
+    n = int(g["sample_rate"] * g.pop("segment_duration"))
+    for seed in (0, 3, 4):
+        x = geometry_clip(seed, n)
+        f32 = F.extract_features(torch.from_numpy(x)[None], **F.geometry_kwargs(**g))[0].numpy()
+        f64 = dft64.features(x, g["sample_rate"], g["n_mels"], g["hop_length"], g["win_length"], g["f_min"], g["f_max"],
+                             g["n_mfcc"])
+        nm = g["n_mels"]
+        assert f32.shape == f64.shape == (nm + 2 * g["n_mfcc"], 1 + n // g["hop_length"])
+        assert np.abs(f32[:nm] - f64[:nm]).max() < 2e-5      # float32 filterbank taps differ from float64 ones by 1e-5
+        assert np.abs(f32[nm:] - f64[nm:]).max() < 5e-5
+
+
 def test_known_answer_silence():
     # all-zero clip: power 0 -> clamp amin -> dB = -100 everywhere, floor = -180 (inactive),
     # mel rows clamp to exactly 0; MFCC c0 = -100*64*sqrt(1/64) = -800 before the z-score.

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build_ab
 /opt/rocm/bin/hipcc -O3 -std=c++20 --offload-arch=gfx950 -fPIC -shared -Wno-unused-function "$@" -o build_ab/lib_$NAME.so \
-    cough_detector_amd/csrc/{api,featurize,spectrogram,resnet,cnn,stream,synth}.hip
+    cough_detector_amd/csrc/{api,featurize,featurize_generic,spectrogram,resnet,cnn,stream,synth}.hip
 echo build_ab/lib_$NAME.so
