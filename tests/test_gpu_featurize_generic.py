@@ -64,7 +64,7 @@ def test_geometry_against_oracle(name):
 def test_every_constructor_flag_on_a_generic_geometry(flags):
     """2 s windows, 80 mel bands up to 8 kHz, 20 MFCCs -- with each flag of the constructor (:43-49)."""
     g = dict(BASE, n_mels=80, n_mfcc=20, f_max=8000.0)
-    kw = {**SHIPPED, **flags}
+    kw = {"use_mfcc": True, **SHIPPED, **flags}
     pre = cda.AudioPreprocessor(device="cuda", segment_duration=2.0, **g, **kw)
     w = torch.from_numpy(np.stack([geometry_clip(s, 32000) for s in (0, 2, 3, 4, 5)]))
     ok = {k: v for k, v in kw.items()}
