@@ -767,7 +767,9 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
                   "cough_cnn_create: unknown dtype %d", dtype);
     COUGH_REQUIRE(w->n_blocks >= 2 && w->n_blocks <= 16, COUGH_EUNSUPPORTED, "cough_cnn_create: %d blocks (need 2..16)", w->n_blocks);
     COUGH_REQUIRE(w->hidden >= 1 && w->hidden <= 256, COUGH_EUNSUPPORTED, "cough_cnn_create: hidden = %d (need 1..256)", w->hidden);
-    const int chunk = dtype == COUGH_DTYPE_FP32 ? 8 : 16;
+    // bf16x3 keeps f32 activations: a layer without a split-bf16 instantiation (x3_band) runs the exact-f32 kernel, so only
+    // that kernel's 8-channel chunk is required; the single-bf16 mode needs 16
+    const int chunk = dtype == COUGH_DTYPE_BF16 ? 16 : 8;
     for (int i = 0; i < w->n_blocks; ++i) {
         const cough_cnn_block& bk = w->blocks[i];
         const cough_conv_bn& p = bk.conv;

@@ -23,6 +23,16 @@ def feature_errors(got: torch.Tensor, ref: torch.Tensor):
     return mel, rel
 
 
+def strict_feature_error(got, ref) -> float:
+    """SURVEY.md 8d's literal form for the z-scored MFCC / delta rows: max |a - b| / max(|b|, 1e-3).  It differs from
+    ``feature_errors`` only where |b| < 1 -- the zero crossings of a unit-variance signal -- where an ABSOLUTE error of a
+    few 1e-6 is divided by up to 1e-3.  Reported next to the oracle's own float32-vs-float64 figure in the same metric
+    (tests/test_gpu_featurize.py::test_strict_survey_metric_is_reported...), which bounds what any float32 path can reach."""
+    got, ref = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
+    d = (got[..., 64:, :] - ref[..., 64:, :]).abs()
+    return (d / ref[..., 64:, :].abs().clamp(min=1e-3)).max().item()
+
+
 def edge_clips() -> dict:
     """Named (16000,) float32 inputs that exercise the branches of the feature chain."""
     rng = np.random.default_rng(1234)

@@ -123,3 +123,31 @@ def test_interface_errors(cnn_golden):
         m.train()(torch.zeros(1, 1, 90, 101))
     with pytest.raises(ValueError, match="Unknown model type"):
         cda.create_model("huge")
+
+
+def test_narrow_channel_tuples_load_under_bf16x3_like_under_fp32():
+    """CoughDetector(channels=...) with 8- or 24-wide blocks loaded under fp32 and must not fail under the
+    engine's default bf16x3: layers the split-bf16 kernel has no instantiation for run on the exact-f32 kernel (f32
+    activations either way).  /root/reference/src/model.py:50-92 takes any channels tuple."""
+    torch.manual_seed(5)
+    x = torch.from_numpy(__import__("numpy").load(
+        __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "features_golden.npz"))["features"][:6])[:, None]
+    for channels in ((8, 24, 32), (24, 40, 64, 128), (16, 32, 64)):
+        ref_model = None
+        sd = None
+        for dtype in ("fp32", "bf16x3"):
+            m = cda.CoughDetector(n_mels=90, channels=channels, compute_dtype=dtype)
+            if sd is None:
+                with torch.no_grad():                                   # non-trivial BatchNorm statistics
+                    for name, buf in m.named_buffers():
+                        if name.endswith("running_mean"):
+                            buf.normal_(0.0, 0.3)
+                        elif name.endswith("running_var"):
+                            buf.uniform_(0.5, 1.5)
+                sd = {k: v.clone() for k, v in m.state_dict().items()}
+                ref_model = ocnn.standard_forward(x, sd)
+            m.load_state_dict(sd)
+            got = m.cuda().eval()(x.cuda()).cpu()
+            err = float((got - ref_model).abs().max())
+            print(f"channels {channels} {dtype}: logits max abs err {err:.2e}")
+            assert err < LOGIT_TOL

@@ -5,7 +5,7 @@ import torch
 
 import cough_detector_amd as cda
 from oracle import dft64, featurizer as ofeat
-from parity import FEAT_TOL, SHIPPED, edge_clips, feature_errors, synth_batch
+from parity import FEAT_TOL, SHIPPED, edge_clips, feature_errors, strict_feature_error, synth_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,29 @@ def test_synthetic_mixture_against_oracle(pre):
     mel, rel = feature_errors(f, ref)
     print(f"synthetic x96: mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
     assert mel < 2e-5 and rel < 2e-5          # measured 3e-6 / 2e-6; spec bound is FEAT_TOL = 1e-4
+
+
+def test_strict_survey_metric_is_reported_next_to_the_oracles_own_float64_error(pre, features_golden):
+    """SURVEY 8d defines the relative error of the z-scored rows with max(|ref|, 1e-3); the suite's
+    metric uses max(|ref|, 1).  Both are computed here on the 32 golden clips, together with the float32 CPU oracle's
+    own distance from the independent float64 re-derivation in the same strict metric: the HIP path must sit within 3x
+    of what the float32 oracle itself achieves (at a zero crossing of a unit-variance row a 4e-6 absolute error reads
+    as 4e-3 'relative'), and within the strict 1e-4 wherever |ref| >= 0.05."""
+    w = synth_batch(0, len(features_golden["seeds"]))
+    got = pre.extract_features(w.cuda()).cpu()
+    ref = torch.from_numpy(features_golden["features"])
+    truth = torch.from_numpy(np.stack([dft64.features(w[i].numpy()) for i in range(w.shape[0])]))
+    hip_strict, oracle_strict = strict_feature_error(got, ref), strict_feature_error(ref, truth)
+    hip_truth = strict_feature_error(got, truth)
+    _, loose = feature_errors(got, ref)
+    d = (got[:, 64:].double() - ref[:, 64:].double()).abs()
+    big = ref[:, 64:].abs() >= 0.05
+    rel_big = (d[big] / ref[:, 64:].double().abs()[big]).max().item()
+    print(f"z-scored rows, 32 goldens: |a-b|/max(|b|,1) = {loose:.2e};  SURVEY 8d strict |a-b|/max(|b|,1e-3): HIP vs oracle "
+          f"{hip_strict:.2e}, oracle(f32) vs float64 {oracle_strict:.2e}, HIP vs float64 {hip_truth:.2e};  max abs {d.max():.2e};  "
+          f"relative where |ref| >= 0.05: {rel_big:.2e}")
+    assert d.max().item() < 2e-5 and rel_big < FEAT_TOL
+    assert hip_truth < 3 * max(oracle_strict, FEAT_TOL) and hip_strict < 3 * max(oracle_strict, FEAT_TOL)
 
 
 @pytest.mark.parametrize("name", sorted(edge_clips().keys()))

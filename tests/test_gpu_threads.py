@@ -1,0 +1,112 @@
+"""The reference's threading pattern on the HIP path (SURVEY.md 8b "Threading"; VERDICT r03 missing #4).
+
+(a) /root/reference/src/inference.py:291-335: the audio callback thread only ENQUEUES chunks (`audio_queue.put`, :296-300);
+    ONE non-main consumer thread drains the queue with `get(timeout=0.5)` and calls `process_audio_chunk` (:302-324).  Here
+    the main thread plays the callback (0.1 s chunks), a consumer thread runs the engine; window probabilities and
+    detections must equal the CPU engine oracle's, i.e. the library is callable from a thread that did not create the
+    handles, with that thread's own current stream.
+(b) include/cough_amd.h: "handles are immutable after creation: any number of host threads may launch with the same
+    handle".  Two threads score different batches through the SAME featuriser / classifier handles, each with its own
+    CoughPipeline (workspace) and its own HIP stream, many times over; every result must be bit-identical to the serial run.
+"""
+import queue
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from cough_detector_amd import synth
+from oracle import engine as oengine
+from parity import SHIPPED, realistic_state_dict, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = dict(model_type="residual", sample_rate=16000, n_mels=64, n_fft=512, hop_length=160, win_length=400,
+              f_min=100.0, f_max=4000.0, segment_duration=1.0, n_mfcc=13, use_mfcc=True, use_pcen=False,
+              use_pre_emphasis=False, pre_emphasis_coef=0.97, use_delta_delta=False, use_spectral_contrast=False,
+              n_contrast_bands=6)
+
+
+def test_consumer_thread_fed_by_a_queue_matches_the_engine_oracle(tmp_path):
+    sd = realistic_state_dict(5)
+    path = str(tmp_path / "m.pt")
+    torch.save({"model_state_dict": sd, "config": CONFIG}, path)
+    clock = {"t": 0.0}
+    eng = cda.CoughDetectorInference(path, confidence_threshold=0.5, smoothing_window=3, debounce_seconds=0.5,
+                                     verbose=False, clock=lambda: clock["t"])          # handles created on the MAIN thread
+    audio_queue, running, hits, errors = queue.Queue(), {"on": True}, [], []
+
+    def process_audio():                                      # inference.py:302-324
+        while running["on"] or not audio_queue.empty():
+            try:
+                t_end, chunk = audio_queue.get(timeout=0.05)
+            except queue.Empty:
+                continue
+            try:
+                clock["t"] = t_end                            # stream time of this chunk (the reference reads the wall clock)
+                result = eng.process_audio_chunk(chunk.flatten())
+                if result is not None:
+                    hits.append((t_end, result[1]))
+            except Exception as e:                            # the reference prints and goes on (:323-324); the test must see it
+                errors.append(e)
+
+    consumer = threading.Thread(target=process_audio, name="consumer")
+    consumer.start()
+    stream = synth.make_stream(9, 6.0)
+    for i in range(0, len(stream) - 1600 + 1, 1600):          # the "audio callback": enqueue a copy, nothing else (:296-300)
+        audio_queue.put(((i + 1600) / 16000.0, stream[i:i + 1600].copy().reshape(-1, 1)))
+    running["on"] = False
+    consumer.join(timeout=120)
+    assert not consumer.is_alive() and not errors, errors
+
+    now = {"t": 0.0}
+    ref = oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"])
+    ref_hits = []
+    for i in range(0, len(stream) - 1600 + 1, 1600):
+        now["t"] = (i + 1600) / 16000.0
+        h = ref.process_audio_chunk(stream[i:i + 1600])
+        if h is not None:
+            ref_hits.append(h)
+    assert len(eng.window_probs) == len(ref.window_probs) == 21
+    assert np.abs(np.array(eng.window_probs) - np.array(ref.window_probs)).max() < 1e-3
+    assert len(ref_hits) >= 2 and [t for t, _ in hits] == pytest.approx([t for t, _ in ref_hits])
+    assert np.abs(np.array([c for _, c in hits]) - np.array([c for _, c in ref_hits])).max() < 1e-3
+
+
+def test_two_threads_share_immutable_handles_on_separate_streams():
+    sd = realistic_state_dict(11)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    model.cuda().eval()
+    batches = [synth_batch(7000 + 600 * k, 300 + 17 * k, peak_normalize=False).cuda() for k in range(2)]
+    serial = [cda.CoughPipeline(pre, model)(b, normalize=True).clone() for b in batches]     # also creates the handles
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            pipe = cda.CoughPipeline(pre, model)              # own workspace, shared handles
+            s = torch.cuda.Stream()
+            start.wait()
+            with torch.cuda.stream(s):
+                ok = True
+                for _ in range(40):                           # overlapping launches from both threads
+                    ok &= bool(torch.equal(pipe(batches[k], normalize=True), serial[k]))
+                    feats = pre.featurize_batch(batches[k], normalize=True)
+                    ok &= bool(torch.equal(model(feats.unsqueeze(1)), serial[k])) if k == 0 else True
+            s.synchronize()
+            results[k] = ok
+        except Exception as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert results == [True, True]
