@@ -96,8 +96,9 @@ struct RbxCfg {
     static_assert(WAVES % NT == 0 && MG * MW * 32 + (TAIL ? 16 : 0) >= M, "tile split");
     static_assert(OW == (XW + 1) / 2, "sub-image row pitch");
     static_assert(M * OP * 4 <= 2 * PL, "the output tile lies over the planes");
-    static_assert((G * NPX * CIN / 4 + THREADS - 1) / THREADS <= 18, "staging registers (f32 input)");
-    static_assert(LDS * 2 <= 160 * 1024, "two workgroups per CU");
+    static constexpr int STAGE_MAX = 18;                                     // 16-byte pieces per thread staged in one batch
+    static_assert((G * NPX * CIN / 4 + THREADS - 1) / THREADS <= 2 * STAGE_MAX, "staging registers (f32 input, two batches)");
+    static_assert(LDS <= 160 * 1024, "one workgroup must fit a CU (two do for the shipped image)");
 };
 
 template <int CIN, int COUT, int G, int XH, int XW>
@@ -158,33 +159,39 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
     {
         constexpr int NPIECE = G * NPX * CIN / 4, UN = (NPIECE + THREADS - 1) / THREADS, QP = CIN / 4;
+        // the shipped image stages in ONE batch (all loads in flight before the first split); a larger image (103- / 110-row
+        // features) in two, so that the staging registers stay within the accumulators' budget
+        constexpr int NB = UN <= Cfg::STAGE_MAX ? 1 : 2, UNB = (UN + NB - 1) / NB;
         const int valid = nvalid * NPX * QP;
         const float4* src = reinterpret_cast<const float4*>(a.x + (long long)clip0 * NPX * CIN);
-        float4 v[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            // unconditional, index-clamped loads: a load under a branch makes the compiler drain vmcnt to 0 before the
-            // first piece is split; clamped, the pieces are processed as they arrive (vmcnt(UN - 1 - u))
-            const int i = tid + u * THREADS;
-            v[u] = src[i < valid ? i : valid - 1];
-        }
         if (tid < 2 * CHI) {   // the zero cell of every chunk plane, hi and lo
             *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = tid + u * THREADS;
-            if (i < NPIECE) {
-                const int P = i / QP, q = i % QP;                      // raster pixel (clip, row, column), quarter-chunk
-                const int g = P / NPX, rem = P % NPX, ih = rem / XW, iw = rem % XW;
-                const int cell = g * NPP + ((ih & 1) ? ((iw & 1) ? Cfg::PB11 : Cfg::PB10) : ((iw & 1) ? Cfg::PB01 : 0)) +
-                                 (ih >> 1) * OW + (iw >> 1);
-                uint2 hi, lo;
-                if (i >= valid) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // clips beyond the batch read as zeros
-                split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
-                const int off = (q >> 1) * CPX + cell * 16 + (q & 1) * 8;
-                *reinterpret_cast<uint2*>(smem + off) = hi;
-                *reinterpret_cast<uint2*>(smem + off + PL) = lo;
+        for (int b0 = 0; b0 < UN; b0 += UNB) {
+            float4 v[UNB];
+#pragma unroll
+            for (int u = 0; u < UNB; ++u) {
+                // unconditional, index-clamped loads: a load under a branch makes the compiler drain vmcnt to 0 before the
+                // first piece is split; clamped, the pieces are processed as they arrive (vmcnt(UNB - 1 - u))
+                const int i = tid + (b0 + u) * THREADS;
+                v[u] = src[i < valid ? i : valid - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNB; ++u) {
+                const int i = tid + (b0 + u) * THREADS;
+                if (i < NPIECE) {
+                    const int P = i / QP, q = i % QP;                      // raster pixel (clip, row, column), quarter-chunk
+                    const int g = P / NPX, rem = P % NPX, ih = rem / XW, iw = rem % XW;
+                    const int cell = g * NPP + ((ih & 1) ? ((iw & 1) ? Cfg::PB11 : Cfg::PB10) : ((iw & 1) ? Cfg::PB01 : 0)) +
+                                     (ih >> 1) * OW + (iw >> 1);
+                    uint2 hi, lo;
+                    if (i >= valid) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // clips beyond the batch read as zeros
+                    split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
+                    const int off = (q >> 1) * CPX + cell * 16 + (q & 1) * 8;
+                    *reinterpret_cast<uint2*>(smem + off) = hi;
+                    *reinterpret_cast<uint2*>(smem + off + PL) = lo;
+                }
             }
         }
     }
@@ -474,13 +481,15 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     if constexpr (COUT == 128) {
         // ---- fused head (model.py:242-247, :257-265): same summation order as tail_kernel (pixels in order, then
         // the lanes of a wave, then the two waves of a clip) ----
-        static_assert(G * 128 == THREADS, "one thread per (clip, channel)");
+        static_assert(G * 128 <= THREADS, "one thread per (clip, channel)");
         if (a.fcw != nullptr) {
             float* hred = reinterpret_cast<float*>(smem + Cfg::HRED);
             const int c = tid & 127, g = tid >> 7;
             float sum = 0.f;
+            if (g < G) {
 #pragma unroll 6
-            for (int i = 0; i < PER; ++i) sum += otile[(g * PER + i) * OP + c];
+                for (int i = 0; i < PER; ++i) sum += otile[(g * PER + i) * OP + c];
+            }
             const float mean = sum / float(PER);
             float l0 = wave_sum(mean * fw0), l1 = wave_sum(mean * fw1);
             if (lane == 0) { hred[wave * 2] = l0; hred[wave * 2 + 1] = l1; }

@@ -988,6 +988,20 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     return COUGH_OK;
 }
 
+#ifndef RBX_G_TALL
+#define RBX_G_TALL 1   // clips per workgroup of block 1 at the 13x13 / 14x13 inputs: 1 (48-52 KB of LDS, three workgroups per CU)
+#endif
+// block-input geometries resblock_x3_kernel is instantiated for (block index, rows, columns)
+inline bool rbx_compiled(int blk, int xh, int xw) {
+    return blk == 0 ? (xw == 25 && (xh == 22 || xh == 26 || xh == 27)) : (xw == 13 && (xh == 11 || xh == 13 || xh == 14));
+}
+
+template <int CIN, int COUT, int G, int XH, int XW>
+void rbx_launch(int n, hipStream_t st, const RbxArgs& ra) {
+    using Cfg = RbxCfg<CIN, COUT, G, XH, XW>;
+    hipLaunchKernelGGL((resblock_x3_kernel<CIN, COUT, G, XH, XW>), dim3((n + G - 1) / G), dim3(Cfg::THREADS), Cfg::LDS, st, ra);
+}
+
 template <typename T>
 int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes& s, float* d_logits, float* d_probs,
                  int* d_preds, char* ws, hipStream_t st, bool stem_done = false) {
@@ -1022,8 +1036,11 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     bool head_done = false;   // the fused block-1 kernel also runs the head
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
-        if constexpr (sizeof(T) == 4) {   // bf16x3: fused split-bf16 block kernels for the shipped 90x101 feature image
-            if (m->dtype == COUGH_DTYPE_BF16X3 && ((i == 0 && k.xh == 22 && k.xw == 25) || (i == 1 && k.xh == 11 && k.xw == 13))) {
+        if constexpr (sizeof(T) == 4) {
+            // bf16x3: fused split-bf16 block kernels, compiled for the block-input geometries of the feature images the
+            // reference's own flags produce at 101 frames -- 90 rows (shipped: 22x25 -> 11x13), 103 rows (constructor
+            // defaults, delta-delta on: 26x25 -> 13x13) and 110 rows (+ contrast / centroid rows: 27x25 -> 14x13)
+            if (m->dtype == COUGH_DTYPE_BF16X3 && rbx_compiled(i, k.xh, k.xw)) {
                 RbxArgs ra{};
                 ra.x = reinterpret_cast<const float*>(k.x);
                 ra.n_clips = n;
@@ -1032,17 +1049,17 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                 ra.b1 = m->d_b[k.s1];
                 ra.b2 = m->d_b[k.s2];
                 ra.out = reinterpret_cast<float*>(k.out);
-                if (i == 0) {
-                    using Cfg = RbxCfg<32, 64, 1, 22, 25>;
-                    hipLaunchKernelGGL((resblock_x3_kernel<32, 64, 1, 22, 25>), dim3(n), dim3(Cfg::THREADS), Cfg::LDS, st, ra);
-                } else {
-                    using Cfg = RbxCfg<64, 128, 2, 11, 13>;
+                if (i == 1) {
                     ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds;
                     if (stem_done) ra.out = nullptr;   // pipeline: nobody reads a3
-                    hipLaunchKernelGGL((resblock_x3_kernel<64, 128, 2, 11, 13>), dim3((n + 1) / 2), dim3(Cfg::THREADS), Cfg::LDS,
-                                       st, ra);
                     head_done = true;
                 }
+                if (i == 0 && k.xh == 22) rbx_launch<32, 64, 1, 22, 25>(n, st, ra);
+                else if (i == 0 && k.xh == 26) rbx_launch<32, 64, 1, 26, 25>(n, st, ra);
+                else if (i == 0) rbx_launch<32, 64, 1, 27, 25>(n, st, ra);
+                else if (k.xh == 11) rbx_launch<64, 128, 2, 11, 13>(n, st, ra);
+                else if (k.xh == 13) rbx_launch<64, 128, RBX_G_TALL, 13, 13>(n, st, ra);
+                else rbx_launch<64, 128, RBX_G_TALL, 14, 13>(n, st, ra);
                 COUGH_HIP_CHECK(hipGetLastError());
                 continue;
             }
@@ -1189,11 +1206,15 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         }
     }
     if (!err && dtype == COUGH_DTYPE_BF16X3) {   // more than 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, 2, 11, 13>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fused[] = {reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
+                               reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 26, 25>),
+                               reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 27, 25>),
+                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, 2, 11, 13>),
+                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, RBX_G_TALL, 13, 13>),
+                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, RBX_G_TALL, 14, 13>)};
+        hipError_t e = hipSuccess;
+        for (const void* fn : fused)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_error("cough_resnet_create: %s", hipGetErrorString(e));
             err = COUGH_EHIP;

@@ -228,15 +228,19 @@ class CoughDetectorResidual(nn.Module):
         """The arithmetic that actually runs for a ``(height, width)`` feature image.  The fused reduced-precision
         kernels are compiled for the shipped ``channels=(32, 64, 128)`` (``cough_resnet_create``); any other tuple
         goes through ``cough_resnet_create_ex`` onto the exact-f32 MFMA kernels, and the split-bf16 residual blocks
-        are compiled for the shipped 90x101 image (block inputs 22x25 and 11x13) -- another image size runs them
-        in exact f32 as well.  Results are at least as accurate as asked for; throughput is the f32 path's."""
+        are compiled for the images the reference's own flags produce at 101 frames -- 90 rows (shipped; block inputs
+        22x25 and 11x13), 103 rows (constructor defaults: delta-delta on; 26x25 / 13x13) and 110 rows (+ contrast and
+        centroid rows; 27x25 / 14x13) -- another image size runs them in exact f32 as well.  Results are at least as
+        accurate as asked for; throughput is the f32 path's."""
         if self.compute_dtype == "fp32":
             return self.compute_dtype
         if self.channels != (32, 64, 128):
             return "fp32"
-        if self.compute_dtype == "bf16x3" and (height, width) != (90, 101):
+        if self.compute_dtype == "bf16x3" and (height, width) not in self.X3_IMAGES:
             return "fp32"
         return self.compute_dtype
+
+    X3_IMAGES = ((90, 101), (103, 101), (110, 101))     # csrc/resnet.hip rbx_compiled()
 
     def _warn_fallback(self, height: int, width: int) -> None:
         eff = self.effective_dtype(height, width)

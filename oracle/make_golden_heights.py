@@ -1,0 +1,75 @@
+"""Goldens of the residual classifier at the OTHER image heights the reference's own flags produce.
+
+Run in the BUILD CONTAINER only (needs ``/root/reference``):   python -m oracle.make_golden_heights
+
+``AudioPreprocessor``'s constructor defaults (``/root/reference/src/preprocessing.py:43-49``: delta-delta on) and the
+engine's missing-key defaults (``/root/reference/src/inference.py:100-106,128-143``) give 103-row (64 mel + 3 x 13) and
+110-row (+ 6 contrast bands + centroid) feature images instead of the shipped 90.  ``CoughDetectorResidual`` is fully
+convolutional (``src/model.py:216-265``), so the SAME conv weights (those of ``resnet_golden.npz``) serve, with the head re-calibrated per height to a trained
+detector's logit scale; this script executes
+the REFERENCE module on 16 inputs of each height and commits the activations after block 1, logits, softmax and argmax
+as ``tests/golden/resnet_heights_golden.npz``.
+
+Inputs: 103 rows = the restated featuriser with the constructor-default flags (pre-emphasis, PCEN, delta-delta) on the
+first 16 golden clips; 110 rows = the same + 7 rows of seeded N(0, 1) noise standing in for the contrast / centroid rows
+(with the default 6 bands the reference's own rows are NaN by construction, which would make every logit NaN).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cough_detector_amd import synth                     # noqa: E402
+from oracle import featurizer                             # noqa: E402
+from oracle.make_golden import load_reference_model_module, OUT   # noqa: E402
+
+N = 16
+
+
+def main():
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(OUT, "resnet_golden.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    ref = load_reference_model_module()
+    net = ref.create_model("residual", n_mels=103, num_classes=2, in_channels=1).eval()
+    print(net.load_state_dict(sd))
+    wav = torch.from_numpy(synth.make_clips(0, N))
+    x103 = featurizer.extract_features_batch(wav, use_pre_emphasis=True, use_pcen=True, use_delta_delta=True).unsqueeze(1)
+    noise = torch.randn(N, 1, 7, x103.shape[-1], generator=torch.Generator().manual_seed(110))
+    out = {}
+    for name, x in (("h103", x103.contiguous()), ("h110", torch.cat([x103, noise], dim=2).contiguous())):
+        with torch.no_grad():
+            # the head of resnet_golden.npz was calibrated on 90-row log-mel images; re-calibrate it on THIS input set
+            # the same way (class-margin std 2.5, both classes present) -- stored per height as fc.2.weight / fc.2.bias
+            net.load_state_dict(sd)
+            l = net(x)
+            net.fc[2].weight.data.mul_(2.5 / (l[:, 1] - l[:, 0]).std())
+            net.fc[2].bias.data.sub_(net(x).mean(dim=0))
+            d = (net(x)[:, 1] - net(x)[:, 0]).sort().values
+            net.fc[2].bias.data[1] -= 0.5 * (d[N // 2 - 1] + d[N // 2])
+            a1 = net.conv1(x)
+            a2 = net.res_blocks[0](a1)
+            a3 = net.res_blocks[1](a2)
+            logits = net(x)
+            preds, probs = net.predict(x)
+        m = logits[:, 1] - logits[:, 0]
+        print(f"{name}: x {tuple(x.shape)} a1 {tuple(a1.shape)} a2 {tuple(a2.shape)} a3 {tuple(a3.shape)}; margin std "
+              f"{m.std():.3f}, min |margin| {m.abs().min():.4f}, max |logit| {logits.abs().max():.3f}, preds {preds.tolist()}")
+        out.update({f"{name}.x": x.numpy(), f"{name}.a3": a3.numpy(), f"{name}.logits": logits.numpy(),
+                    f"{name}.probs": probs.numpy(), f"{name}.preds": preds.numpy(),
+                    f"{name}.a1_shape": np.array(a1.shape), f"{name}.a2_shape": np.array(a2.shape),
+                    f"{name}.fc.2.weight": net.fc[2].weight.detach().numpy().copy(),
+                    f"{name}.fc.2.bias": net.fc[2].bias.detach().numpy().copy()})
+    path = os.path.join(OUT, "resnet_heights_golden.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()

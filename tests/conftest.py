@@ -41,6 +41,24 @@ def resnet_golden():
 
 
 @pytest.fixture(scope="session")
+def resnet_heights_golden(resnet_golden):
+    """{"h103" | "h110": (state_dict, vectors)}: the reference module on 103- and 110-row images
+    (oracle/make_golden_heights.py); the conv weights of resnet_golden.npz, the head re-calibrated per height."""
+    import numpy as np
+    import torch
+    base_sd, _ = resnet_golden
+    g = np.load(os.path.join(GOLDEN, "resnet_heights_golden.npz"))
+    out = {}
+    for name in ("h103", "h110"):
+        sd = dict(base_sd)
+        sd["fc.2.weight"] = torch.from_numpy(g[name + ".fc.2.weight"])
+        sd["fc.2.bias"] = torch.from_numpy(g[name + ".fc.2.bias"])
+        vec = {k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".") and ".fc.2." not in k}
+        out[name] = (sd, vec)
+    return out
+
+
+@pytest.fixture(scope="session")
 def resnet_channels_golden():
     """{case: (channels, state_dict, vectors)} for non-default ``channels`` tuples (oracle/make_golden_channels.py);
     the inputs are the first clips of features_golden.npz."""

@@ -258,6 +258,8 @@ def test_effective_dtype_reports_the_kernels_that_run():
     import cough_detector_amd as cda
     m = cda.create_model("residual", n_mels=90, compute_dtype="bf16x3")
     assert m.compute_dtype == "bf16x3" and m.effective_dtype() == "bf16x3" and m.effective_dtype(64, 101) == "fp32"
+    assert m.effective_dtype(103, 101) == "bf16x3" and m.effective_dtype(110, 101) == "bf16x3"     # the reference's own flags
+    assert m.effective_dtype(95, 101) == "fp32" and m.effective_dtype(103, 201) == "fp32"
     wide = cda.CoughDetectorResidual(channels=(16, 24, 40), compute_dtype="bf16x3")
     assert wide.effective_dtype() == "fp32" and wide.compute_dtype == "bf16x3"
     assert cda.create_model("residual", compute_dtype="fp32").effective_dtype(33, 77) == "fp32"
