@@ -113,6 +113,7 @@ __device__ __forceinline__ int fdiv(int a, int b, float inv) {
 // with a zero border (rows/cols -3..), so every A fragment is 4 aligned ds_read_b32.  K is re-ordered as
 // 8 kernel rows x 8 taps (7 + one zero tap; the 8th row is all zero): MFMA step s, lane half h <-> kernel
 // row 2s+h, element jj <-> tap jj, i.e. 8 consecutive input pixels of one image row per lane.
+constexpr int STEM_SB_MAXL = 22;   // 2 * 256 * 22 = 11 264 pixels: the 110 x 101 image of the reference's default flags fits
 struct StemLds {
     int nrows, pitch;   // bf16 image in LDS: row = ih + 3, col = iw + 3, pitch even
     size_t bytes;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     // stage: all of this thread's 8-byte global loads are issued first (the clip is one linear run of
     // H*W floats, 8-byte aligned for every clip when H*W is even), the image is zero-filled meanwhile,
     // then the pairs are converted to bf16 and written to their (row, col) cells
-    constexpr int SB_MAXL = 20;                      // float2 loads per thread (H*W <= 2*256*20)
+    constexpr int SB_MAXL = STEM_SB_MAXL;            // float2 loads per thread (H*W <= 2*256*SB_MAXL)
     const int npairs = (H * W + 1) / 2;
     const bool even = ((H * W) & 1) == 0;
     float2 pv[SB_MAXL];
@@ -988,9 +989,9 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     return COUGH_OK;
 }
 
-#ifndef RBX_G_TALL
-#define RBX_G_TALL 1   // clips per workgroup of block 1 at the 13x13 / 14x13 inputs: 1 (48-52 KB of LDS, three workgroups per CU)
-#endif
+// clips per workgroup of block 1 at the 13x13 / 14x13 inputs: 1 (48-52 KB of LDS, three workgroups per CU; two clips per
+// workgroup = 95-102 KB, one workgroup per CU, measured the same: profiles/r04_heights.txt)
+constexpr int RBX_G_TALL = 1;
 // block-input geometries resblock_x3_kernel is instantiated for (block index, rows, columns)
 inline bool rbx_compiled(int blk, int xh, int xw) {
     return blk == 0 ? (xw == 25 && (xh == 22 || xh == 26 || xh == 27)) : (xw == 13 && (xh == 11 || xh == 13 || xh == 14));
@@ -1009,13 +1010,13 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     const long long n_pool = (long long)n * s.P1h * s.P1w;
     if (stem_done) {
         // a1 was produced by the featurise kernel (cough_pipeline_forward)
-    } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
+    } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * STEM_SB_MAXL) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
             hipLaunchKernelGGL(stem_bf16_kernel<false>, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
                                l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1));
         }
-    } else if (m->dtype == COUGH_DTYPE_BF16X3 && 2 * stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * 20) {
+    } else if (m->dtype == COUGH_DTYPE_BF16X3 && 2 * stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * STEM_SB_MAXL) {
         if constexpr (sizeof(T) == 4) {
             const StemLds l = stem_lds(s);
             hipLaunchKernelGGL(stem_bf16_kernel<true>, dim3(n), dim3(256), 2 * l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
