@@ -72,14 +72,10 @@ struct RbxCfg {
     static constexpr int NT = COUT / 32, MG = WAVES / NT, TILES = (M + 31) / 32;
     // TAIL: the last M % 32 <= 16 rows are not padded to a 32-row tile (block 0: 143 rows = 4 tiles + 15 rows would
     // waste 17 of 160 rows AND leave the waves with 3 / 3 / 2 / 2 tiles); they form one 16-row tile that the four waves
-    // share by channels (TW 16-channel tiles each: 1 in block 0, 2 in a one-clip block 1) on v_mfma_f32_16x16x32_bf16:
-    // every wave then owns FULL / MG 32x32 tiles + TW 16x16 tiles -- the same work for each, 143 of 144 rows useful.
-    static constexpr int NT16 = COUT / 16, TW = NT16 / WAVES > 0 ? NT16 / WAVES : 1;   // 16-channel tiles of the 16-row tile per wave
-#ifndef RBX_FUSED_NOTAIL
-#define RBX_FUSED_NOTAIL 0   // experiment: the one-clip block 1 of the fused kernel pads its 42 rows to two 32-row tiles
-#endif
-    static constexpr bool TAIL = M % 32 != 0 && M % 32 <= 16 && NT16 % WAVES == 0 && TW <= 2 && (M / 32) % MG == 0 &&
-                                 (9 * CIN / 16) % 2 == 0 && (CIN / 16) % 2 == 0 && !(RBX_FUSED_NOTAIL && TW == 2);
+    // share by channels (16 each) on v_mfma_f32_16x16x32_bf16: every wave then owns FULL / MG 32x32 tiles + one
+    // 16x16 tile -- the same work for each, 143 of 144 rows useful.
+    static constexpr bool TAIL = M % 32 != 0 && M % 32 <= 16 && COUT / 16 == WAVES && (M / 32) % MG == 0 &&
+                                 (9 * CIN / 16) % 2 == 0 && (CIN / 16) % 2 == 0;
     static constexpr int FULL = TAIL ? M / 32 : TILES;                 // 32-row tiles
     static constexpr int MW = (FULL + MG - 1) / MG;
     static constexpr int KS1 = 9 * CIN / 16, KSP = CIN / 16, KS2 = 9 * COUT / 16, KS = KS1 + KSP + KS2;
@@ -105,11 +101,8 @@ struct RbxCfg {
     static_assert(LDS <= 160 * 1024, "one workgroup must fit a CU (two do for the shipped image)");
 };
 
-// STAGE: the input is staged from a.x (f32, HBM); false: the caller left it, split, in the x planes (fused blocks).
-// SINK 0: output -> f32 tile in LDS -> a.out (+ the fused head of block 1); 1: output split into the x planes of the NEXT
-// block (RbxCfg<COUT, 2 COUT, 1, OH, OW>) in LDS, a.out (nullable) written straight from the accumulators.
-template <int CIN, int COUT, int G, int XH, int XW, bool STAGE, int SINK>
-__device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int clip0, const int nvalid) {
+template <int CIN, int COUT, int G, int XH, int XW>
+__global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
     using Cfg = RbxCfg<CIN, COUT, G, XH, XW>;
     constexpr int THREADS = Cfg::THREADS, OH = Cfg::OH, OW = Cfg::OW, NPX = Cfg::NPX, PER = Cfg::PER, M = Cfg::M;
     constexpr int NT = Cfg::NT, MW = Cfg::MW, KS1 = Cfg::KS1, KSP = Cfg::KSP, KS = Cfg::KS;
@@ -127,11 +120,14 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
 #define RBX_PRIO 0
 #endif
     constexpr int D = RBX_D;   // weight prefetch depth (k-steps; one k-step = MW x 3 MFMAs >= 192 cycles)
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     float* lbias = reinterpret_cast<float*>(smem + Cfg::BIAS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int ng = wave % NT, mg = wave / NT;
-    if constexpr (STAGE) RB_STAMP(0);
+    const int clip0 = blockIdx.x * G;
+    const int nvalid = a.n_clips - clip0 < G ? a.n_clips - clip0 : G;
+    RB_STAMP(0);
 
     // biases first: vector-memory loads return in issue order, so a bias loaded after the staging loads and stored
     // to LDS straight away would drain every load of wave 0 before its first piece is split
@@ -146,26 +142,22 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
     bf16x8 ring[D][2];
 #pragma unroll
     for (int i = 0; i < D; ++i) { ring[i][0] = wfrag(i, 0); ring[i][1] = wfrag(i, 1); }
-    // TAIL: this wave's TW 16-channel tiles (wave * TW + j) of the 16-row tile, in k32-steps
-    constexpr int DT = D / 2 > 0 ? D / 2 : 1, TW = Cfg::TW;
-    const bf16_t* wtbase = TAIL ? a.wt + size_t(wave * TW) * 1024 + lane * 8 : nullptr;
-    auto wtfrag = [&](int q, int plane, int jt) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(wtbase + ((size_t(q) * Cfg::NT16 + jt) * 2 + plane) * 512);
+    // TAIL: this wave's 16 channels (tile `wave`) of the 16-row tile, in k32-steps
+    constexpr int DT = D / 2 > 0 ? D / 2 : 1;
+    const bf16_t* wtbase = TAIL ? a.wt + size_t(wave) * 1024 + lane * 8 : nullptr;
+    auto wtfrag = [&](int q, int plane) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(wtbase + (size_t(q) * Cfg::WAVES * 2 + plane) * 512);
     };
-    bf16x8 tring[DT][TW][2];
+    bf16x8 tring[DT][2];
     if constexpr (TAIL) {
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int jt = 0; jt < TW; ++jt) { tring[i][jt][0] = wtfrag(i, 0, jt); tring[i][jt][1] = wtfrag(i, 1, jt); }
+        for (int i = 0; i < DT; ++i) { tring[i][0] = wtfrag(i, 0); tring[i][1] = wtfrag(i, 1); }
     }
-    const int tch = 16 * wave * TW;   // TAIL: the first of the 16 * TW output channels this wave owns in the 16-row tile
+    const int tch = 16 * wave;   // TAIL: the 16 output channels this wave owns in the 16-row tile
 
     // ---- stage: the clips' x (f32) is one linear run of 16-byte pieces = 4 channels of one pixel; all loads are
     // issued first, then each piece is split and its hi / lo halves go to the swizzled chunk of the two planes ----
-    if constexpr (!STAGE) {
-        if (tid < 2 * CHI) *reinterpret_cast<uint4*>(smem + (tid / CHI) * PL + (tid % CHI) * CPX + ZX) = make_uint4(0, 0, 0, 0);
-    } else {
+    {
         constexpr int NPIECE = G * NPX * CIN / 4, UN = (NPIECE + THREADS - 1) / THREADS, QP = CIN / 4;
         // the shipped image stages in ONE batch (all loads in flight before the first split); a larger image (103- / 110-row
         // features) in two, so that the staging registers stay within the accumulators' budget
@@ -255,9 +247,7 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
         f32x16 acc1[MWX], acc2[MWX];
 #pragma unroll
         for (int mt = 0; mt < MWX; ++mt) { acc1[mt] = f32x16{0}; acc2[mt] = f32x16{0}; }
-        f32x4 tacc1[TW], tacc2[TW];
-#pragma unroll
-        for (int jt = 0; jt < TW; ++jt) { tacc1[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc2[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        f32x4 tacc1 = {0.f, 0.f, 0.f, 0.f}, tacc2 = {0.f, 0.f, 0.f, 0.f};
         bf16x8 taf[2];
         int ttadr = 0;
         // TAIL fragments of k32-step q (q counts 32-wide steps through conv1, projection, conv2)
@@ -361,18 +351,15 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
                     }
                 }
                 if constexpr (TAIL) {
-#pragma unroll
-                    for (int jt = 0; jt < TW; ++jt) {
-                        const int n0 = tch + 16 * jt + 4 * tq;
-                        const float4 bb = *reinterpret_cast<const float4*>(lbias + n0);
-                        uint2 hi, lo;
-                        split4(fmaxf(tacc1[jt][0] + bb.x, 0.f), fmaxf(tacc1[jt][1] + bb.y, 0.f), fmaxf(tacc1[jt][2] + bb.z, 0.f),
-                               fmaxf(tacc1[jt][3] + bb.w, 0.f), hi, lo);
-                        if (rokt) {
-                            const int off = (n0 >> 3) * CPH + Rt * 16 + ((n0 >> 2) & 1) * 8;
-                            *reinterpret_cast<uint2*>(smem + off) = hi;
-                            *reinterpret_cast<uint2*>(smem + off + PL) = lo;
-                        }
+                    const int n0 = tch + 4 * tq;
+                    const float4 bb = *reinterpret_cast<const float4*>(lbias + n0);
+                    uint2 hi, lo;
+                    split4(fmaxf(tacc1[0] + bb.x, 0.f), fmaxf(tacc1[1] + bb.y, 0.f), fmaxf(tacc1[2] + bb.z, 0.f),
+                           fmaxf(tacc1[3] + bb.w, 0.f), hi, lo);
+                    if (rokt) {
+                        const int off = (n0 >> 3) * CPH + Rt * 16 + ((n0 >> 2) & 1) * 8;
+                        *reinterpret_cast<uint2*>(smem + off) = hi;
+                        *reinterpret_cast<uint2*>(smem + off + PL) = lo;
                     }
                 }
                 __syncthreads();
@@ -420,30 +407,19 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
                 if constexpr (s % 2 == 0) {
                     tfrag(std::integral_constant<int, q>{});
                 } else {
-                    bf16x8 twhi[TW], twlo[TW];
-#pragma unroll
-                    for (int jt = 0; jt < TW; ++jt) {
-                        twhi[jt] = tring[q % DT][jt][0];
-                        twlo[jt] = tring[q % DT][jt][1];
-                        if constexpr (q + DT < KS / 2) {
-                            tring[q % DT][jt][0] = wtfrag(q + DT, 0, jt);
-                            tring[q % DT][jt][1] = wtfrag(q + DT, 1, jt);
-                        }
-                    }
+                    const bf16x8 twhi = tring[q % DT][0], twlo = tring[q % DT][1];
+                    if constexpr (q + DT < KS / 2) { tring[q % DT][0] = wtfrag(q + DT, 0); tring[q % DT][1] = wtfrag(q + DT, 1); }
 #if RBX_PIN
                     __builtin_amdgcn_sched_barrier(0);
 #endif
-#pragma unroll
-                    for (int jt = 0; jt < TW; ++jt) {
-                        if constexpr (s < KS1) {
-                            tacc1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi[jt], taf[0], tacc1[jt], 0, 0, 0);
-                            tacc1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi[jt], taf[1], tacc1[jt], 0, 0, 0);
-                            tacc1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo[jt], taf[0], tacc1[jt], 0, 0, 0);
-                        } else {
-                            tacc2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi[jt], taf[0], tacc2[jt], 0, 0, 0);
-                            tacc2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi[jt], taf[1], tacc2[jt], 0, 0, 0);
-                            tacc2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo[jt], taf[0], tacc2[jt], 0, 0, 0);
-                        }
+                    if constexpr (s < KS1) {
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[0], tacc1, 0, 0, 0);
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[1], tacc1, 0, 0, 0);
+                        tacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo, taf[0], tacc1, 0, 0, 0);
+                    } else {
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[0], tacc2, 0, 0, 0);
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twhi, taf[1], tacc2, 0, 0, 0);
+                        tacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twlo, taf[0], tacc2, 0, 0, 0);
                     }
 #if RBX_PIN
                     __builtin_amdgcn_sched_barrier(0);
@@ -455,31 +431,13 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
             (step.template operator()<Ss>(), ...);
         }(std::make_integer_sequence<int, KS>{});
 
-        // ---- epilogue: out = ReLU(conv2 + projection + b2) -> f32 [pixel][COUT] tile over the (dead) planes (SINK 0), or
-        // split (hi, lo) into the NEXT block's x planes at the pixel's parity-split cell (SINK 1) ----
+        // ---- epilogue: out = ReLU(conv2 + projection + b2) -> f32 [pixel][COUT] tile over the (dead) planes ----
         RB_STAMP(5);
 #if RBX_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         __syncthreads();
         float* otile = reinterpret_cast<float*>(smem);
-        auto emit = [&](int R, int n0, float4 o) {   // 4 consecutive channels n0.. of output pixel R
-            if constexpr (SINK == 0) {
-                *reinterpret_cast<float4*>(otile + R * OP + n0) = o;
-            } else {
-                static_assert(SINK == 0 || G == 1, "the fused hand-off is per clip");
-                using Nx = RbxCfg<COUT, 2 * COUT, 1, OH, OW>;
-                const int oh = R / OW, ow = R - oh * OW;
-                const int cell = ((oh & 1) ? ((ow & 1) ? Nx::PB11 : Nx::PB10) : ((ow & 1) ? Nx::PB01 : 0)) + (oh >> 1) * Nx::OW + (ow >> 1);
-                uint2 hi, lo;
-                split4(o.x, o.y, o.z, o.w, hi, lo);
-                const int off = (n0 >> 3) * Nx::CPX + cell * 16 + ((n0 >> 2) & 1) * 8;
-                *reinterpret_cast<uint2*>(smem + off) = hi;
-                *reinterpret_cast<uint2*>(smem + off + Nx::PL) = lo;
-                if (a.out != nullptr && nvalid > 0)   // parity tap of the intermediate activation (cough_resnet_forward)
-                    *reinterpret_cast<float4*>(a.out + ((long long)clip0 * PER + R) * COUT + n0) = o;
-            }
-        };
 #pragma unroll
         for (int mt = 0; mt < MWX; ++mt) {
             const int R = (mg * MW + mt) * 32 + r;
@@ -489,18 +447,15 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
                 const float4 bb = *reinterpret_cast<const float4*>(lbias + COUT + n0);
                 const float4 o = make_float4(fmaxf(acc2[mt][4 * gq] + bb.x, 0.f), fmaxf(acc2[mt][4 * gq + 1] + bb.y, 0.f),
                                              fmaxf(acc2[mt][4 * gq + 2] + bb.z, 0.f), fmaxf(acc2[mt][4 * gq + 3] + bb.w, 0.f));
-                if (rok[mt]) emit(R, n0, o);
+                if (rok[mt]) *reinterpret_cast<float4*>(otile + R * OP + n0) = o;
             }
         }
         if constexpr (TAIL) {
-#pragma unroll
-            for (int jt = 0; jt < TW; ++jt) {
-                const int n0 = tch + 16 * jt + 4 * tq;
-                const float4 bb = *reinterpret_cast<const float4*>(lbias + COUT + n0);
-                const float4 o = make_float4(fmaxf(tacc2[jt][0] + bb.x, 0.f), fmaxf(tacc2[jt][1] + bb.y, 0.f),
-                                             fmaxf(tacc2[jt][2] + bb.z, 0.f), fmaxf(tacc2[jt][3] + bb.w, 0.f));
-                if (rokt) emit(Rt, n0, o);
-            }
+            const int n0 = tch + 4 * tq;
+            const float4 bb = *reinterpret_cast<const float4*>(lbias + COUT + n0);
+            const float4 o = make_float4(fmaxf(tacc2[0] + bb.x, 0.f), fmaxf(tacc2[1] + bb.y, 0.f),
+                                         fmaxf(tacc2[2] + bb.z, 0.f), fmaxf(tacc2[3] + bb.w, 0.f));
+            if (rokt) *reinterpret_cast<float4*>(otile + Rt * OP + n0) = o;
         }
     };
     // a wave whose last tile lies entirely beyond the M valid rows runs the shorter body (one wave-uniform choice)
@@ -514,7 +469,6 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
     }
     __syncthreads();
     RB_STAMP(6);
-    if constexpr (SINK != 0) return;   // the next block's planes are complete (the barrier above)
     const float* otile = reinterpret_cast<const float*>(smem);
     if (a.out != nullptr) {
         const int nvec = nvalid * PER * (COUT / 4);
@@ -557,31 +511,6 @@ __device__ __forceinline__ void rbx_run(const RbxArgs& a, char* smem, const int 
         }
     }
     RB_STAMP(7);
-}
-
-template <int CIN, int COUT, int G, int XH, int XW>
-__global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    const int clip0 = blockIdx.x * G;
-    rbx_run<CIN, COUT, G, XH, XW, true, 0>(a, smem, clip0, a.n_clips - clip0 < G ? a.n_clips - clip0 : G);
-}
-
-// Both residual blocks of one clip in one workgroup: block 0's epilogue leaves its output a2 --
-// split, in block 1's plane order -- in the LDS its own planes no longer need, and block 1 runs on it at G = 1 (one
-// 32-row tile + the 16-row tile for its 42 pixels: 48 rows, the same 87.5 % as 96 for 84).  a2 never leaves the CU and
-// block 1 has no staging phase.  a.b0.out (nullable) receives a2 for the activation tap.
-struct RbxFusedArgs {
-    RbxArgs b0, b1;
-};
-template <int XH, int XW>
-__global__ __launch_bounds__(256, 2) void resblock_x3_fused_kernel(RbxFusedArgs a) {
-    using C0 = RbxCfg<32, 64, 1, XH, XW>;
-    using C1 = RbxCfg<64, 128, 1, C0::OH, C0::OW>;
-    static_assert(C1::LDS <= C0::LDS, "block 1 runs inside block 0's LDS");
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    const int clip0 = blockIdx.x;
-    rbx_run<32, 64, 1, XH, XW, true, 1>(a.b0, smem, clip0, 1);
-    rbx_run<64, 128, 1, C0::OH, C0::OW, false, 0>(a.b1, smem, clip0, 1);
 }
 
 // Host: folded [N][K] weights of conv1, projection and conv2 -> split-bf16 MFMA fragments in stream order.

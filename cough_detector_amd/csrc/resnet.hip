@@ -989,9 +989,6 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
     return COUGH_OK;
 }
 
-#ifndef RBX_FUSED
-#define RBX_FUSED 0
-#endif
 // clips per workgroup of block 1 at the 13x13 / 14x13 inputs: 1 (48-52 KB of LDS, three workgroups per CU; two clips per
 // workgroup = 95-102 KB, one workgroup per CU, measured the same: profiles/r04_heights.txt)
 constexpr int RBX_G_TALL = 1;
@@ -1044,24 +1041,6 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
             // bf16x3: fused split-bf16 block kernels, compiled for the block-input geometries of the feature images the
             // reference's own flags produce at 101 frames -- 90 rows (shipped: 22x25 -> 11x13), 103 rows (constructor
             // defaults, delta-delta on: 26x25 -> 13x13) and 110 rows (+ contrast / centroid rows: 27x25 -> 14x13)
-#if RBX_FUSED
-            if (m->dtype == COUGH_DTYPE_BF16X3 && i == 0 && k.xh == 22 && k.xw == 25) {
-                // both blocks of a clip in one workgroup: a2 stays in LDS (resblock_x3_fused_kernel)
-                RbxFusedArgs fa{};
-                fa.b0.x = reinterpret_cast<const float*>(blk[0].x);
-                fa.b0.n_clips = fa.b1.n_clips = n;
-                fa.b0.wf = m->d_wx3[0]; fa.b0.wt = m->d_wx3t[0]; fa.b0.b1 = m->d_b[blk[0].s1]; fa.b0.b2 = m->d_b[blk[0].s2];
-                fa.b0.out = stem_done ? nullptr : reinterpret_cast<float*>(blk[0].out);   // a2: only the activation tap reads it
-                fa.b1.wf = m->d_wx3[1]; fa.b1.wt = m->d_wx3t[1]; fa.b1.b1 = m->d_b[blk[1].s1]; fa.b1.b2 = m->d_b[blk[1].s2];
-                fa.b1.out = stem_done ? nullptr : reinterpret_cast<float*>(blk[1].out);
-                fa.b1.fcw = m->d_fcw; fa.b1.fcb = m->d_fcb; fa.b1.logits = d_logits; fa.b1.probs = d_probs; fa.b1.preds = d_preds;
-                constexpr size_t fused_lds = RbxCfg<32, 64, 1, 22, 25>::LDS;
-                hipLaunchKernelGGL((resblock_x3_fused_kernel<22, 25>), dim3(n), dim3(256), fused_lds, st, fa);
-                COUGH_HIP_CHECK(hipGetLastError());
-                head_done = true;
-                break;
-            }
-#endif
             if (m->dtype == COUGH_DTYPE_BF16X3 && rbx_compiled(i, k.xh, k.xw)) {
                 RbxArgs ra{};
                 ra.x = reinterpret_cast<const float*>(k.x);
@@ -1228,8 +1207,7 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         }
     }
     if (!err && dtype == COUGH_DTYPE_BF16X3) {   // more than 64 KB of dynamic LDS
-        const void* fused[] = {reinterpret_cast<const void*>(resblock_x3_fused_kernel<22, 25>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
+        const void* fused[] = {reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
                                reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 26, 25>),
                                reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 27, 25>),
                                reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, 2, 11, 13>),
