@@ -89,6 +89,117 @@ __global__ __launch_bounds__(256) void cnn_first_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ first block, split-bf16
+// The first ConvBlock (1 input channel, 3x3, pad 1, BN, ReLU, 2x2 max) on the matrix cores with the stem's image trick
+// (resnet.hip: stem_bf16_kernel<true>): one workgroup per clip stages the (H, W) feature image ONCE as two bf16 images
+// (hi, lo) with a zero border in LDS; the 9 taps fill ONE 16-wide k-step -- k = 4 kh + kw', kw' = 0..3 (the 4th tap and
+// the 4th kernel row carry zero weights), so a lane's fragment is 4 consecutive image pixels of two rows: three aligned
+// ds_read_b32 + two v_alignbyte per row.  GEMM rows are ordered (pool window, dy, dx): the 2x2 max is a max over 4
+// accumulator registers.  Three MFMAs per tile (hi*hi + lo*hi + hi*lo), f32 NHWC output.  r03's f32 VALU kernel
+// (cnn_first_kernel) spent 0.27-0.54 ms per 4096 clips here; it stays for the other dtypes / shapes.
+constexpr int CNN_FIRST_MAXL = 22;   // float2 loads per thread: H * W <= 2 * 256 * 22 = 11 264 (the 110 x 101 image fits)
+struct FirstLds { int nrows, pitch; size_t bytes; };
+inline FirstLds first_lds(int H, int W) {
+    FirstLds l;
+    l.nrows = H + 3;                       // rows -1 .. H + 1 (the row below the last conv row is read with zero weights)
+    l.pitch = (W + 7) & ~1;                // cols -1 .. W + 4, even (dword-aligned pairs)
+    l.bytes = size_t(l.nrows) * l.pitch * 2;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void cnn_first_x3_kernel(const float* __restrict__ feat, int H, int W, int OH, int OW,
+                                                           int nrows, int pitch, const bf16_t* __restrict__ wfrag /* [2][64][8] */,
+                                                           const float* __restrict__ bias, int N, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem_f);
+    const int plane = nrows * pitch;   // even
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const long long clip = blockIdx.x;
+    const float* src = feat + clip * (long long)H * W;
+    const int npairs = (H * W + 1) / 2;
+    const bool even = ((H * W) & 1) == 0;
+    float2 pv[CNN_FIRST_MAXL];
+#pragma unroll
+    for (int u = 0; u < CNN_FIRST_MAXL; ++u) {   // all loads in flight before the first conversion
+        const int p = tid + u * 256;
+        pv[u] = make_float2(0.f, 0.f);
+        if (p < npairs) {
+            if (even) pv[u] = reinterpret_cast<const float2*>(src)[p];
+            else { pv[u].x = src[2 * p]; if (2 * p + 1 < H * W) pv[u].y = src[2 * p + 1]; }
+        }
+    }
+    for (int i = tid; i < 2 * plane / 8; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = (2 * plane / 8) * 8 + tid; i < 2 * plane; i += 256) img[i] = 0;
+    __syncthreads();
+    auto put = [&](int idx, float v) {
+        const bf16_t hi = f2bf(v);
+        img[idx] = hi;
+        img[plane + idx] = f2bf(v - bf2f(hi));
+    };
+    const float inv_w = 1.0f / float(W);
+#pragma unroll
+    for (int u = 0; u < CNN_FIRST_MAXL; ++u) {
+        const int e = 2 * (tid + u * 256);
+        if (e < H * W) {
+            int ih = __float2int_rz(__int2float_rn(e) * inv_w);
+            ih -= (ih * W > e);
+            ih += ((ih + 1) * W <= e);
+            const int iw = e - ih * W;
+            put((ih + 1) * pitch + iw + 1, pv[u].x);
+            if (e + 1 < H * W) {
+                const int ih1 = iw + 1 < W ? ih : ih + 1, iw1 = iw + 1 < W ? iw + 1 : 0;
+                put((ih1 + 1) * pitch + iw1 + 1, pv[u].y);
+            }
+        }
+    }
+    const bf16x8 bw_hi = *reinterpret_cast<const bf16x8*>(wfrag + lane * 8);
+    const bf16x8 bw_lo = *reinterpret_cast<const bf16x8*>(wfrag + 512 + lane * 8);
+    const float bn = r < N ? bias[r] : 0.f;
+    __syncthreads();
+
+    const int n_win = OH * OW, n_tiles = (n_win + 7) / 8;
+    const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
+    const float inv_ow = 1.0f / float(OW);
+    float* o = out + clip * (long long)n_win * N;
+    for (int tile = wave; tile < n_tiles; tile += 4) {
+        int win = tile * 8 + q;
+        if (win >= n_win) win = n_win - 1;
+        int py = __float2int_rz(__int2float_rn(win) * inv_ow);
+        py -= (py * OW > win);
+        py += ((py + 1) * OW <= win);
+        const int px = win - py * OW;
+        const int y = 2 * py + dy, x = 2 * px + dx;             // conv pixel; bordered image: row y + kh, col x + kw'
+        const int rowA = y + 2 * h, rowB = h ? rowA : rowA + 1;  // h = 0: kernel rows 0, 1; h = 1: kernel row 2 (+ a zero-weight row)
+        const int cb = x & ~1;
+        const unsigned sh = 2u * unsigned(x & 1);
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(img + rowA * pitch + cb);
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(img + rowB * pitch + cb);
+        union { uint32_t u[4]; bf16x8 v; } ah, al;
+        {
+            const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+            ah.u[0] = __builtin_amdgcn_alignbyte(a1, a0, sh); ah.u[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+            ah.u[2] = __builtin_amdgcn_alignbyte(b1, b0, sh); ah.u[3] = __builtin_amdgcn_alignbyte(b2, b1, sh);
+        }
+        {
+            const uint32_t* qa = pa + plane / 2;
+            const uint32_t* qb = pb + plane / 2;
+            const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+            al.u[0] = __builtin_amdgcn_alignbyte(a1, a0, sh); al.u[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+            al.u[2] = __builtin_amdgcn_alignbyte(b1, b0, sh); al.u[3] = __builtin_amdgcn_alignbyte(b2, b1, sh);
+        }
+        f32x16 acc = {0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bw_hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bw_hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bw_lo, acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wo = tile * 8 + 2 * g + h;
+            const float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+            if (wo < n_win && r < N) o[(long long)wo * N + r] = fmaxf(v + bn, 0.f);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dense blocks
 template <typename T>
 struct CnnConvArgs {
@@ -350,7 +461,6 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_kernel(CnnLdsArgs a) {
 // operands are 0.1-0.3 off.  Activations cross HBM as f32 (NHWC) and are split while they are staged into TWO swizzled
 // LDS images; weights arrive as (hi, lo) MFMA fragments [k-step][n-tile][2][64 lanes][8]; blockIdx.y selects a group
 // of NT 32-channel tiles (128 -> 256 channels: two groups).
-constexpr int CNN_X3_UNP = 24;   // 16-byte f32 pieces (4 channels) of the band per thread: 2 images <= 96 KB
 struct CnnX3Args {
     const float* in;      // NHWC [B][H][W][CIN] f32
     const bf16_t* wf;     // [9 * CIN / 16][ntot][2 = hi, lo][64][8]
@@ -362,13 +472,20 @@ struct CnnX3Args {
     int ntot;             // 32-channel tiles of the layer
 };
 
-template <int CIN, int NT, int MW, bool POOL>
-__global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
-    constexpr int QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1;
+// The workgroup is WM x WN waves: wave (wm, wn) owns MW 32-row tiles x NT / WN 32-channel tiles of the band, so the band
+// image is staged ONCE for all NT tiles while a wave's accumulators are MW * NT / WN * 16 registers (r03: one N-wave, 128
+// AGPRs + 140-156 VGPRs = one wave per SIMD).  PIECES: 16-byte f32 pieces (4 channels of a pixel) the band may hold =
+// LDS bytes of its two images / 16.
+template <int CIN, int NT, int MW, bool POOL, int WM, int WN, int PIECES>
+__global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
+    constexpr int QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1, THREADS = 64 * WM * WN, NTW = NT / WN;
+    constexpr int UNP = (PIECES + THREADS - 1) / THREADS;   // 16-byte pieces per thread
+    static_assert(NT % WN == 0, "channel tiles split evenly over the N-waves");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
     const int clip = blockIdx.x / a.n_bands, band = blockIdx.x - clip * a.n_bands;
-    const int nt0 = blockIdx.y * NT, N = 32 * a.ntot;
+    const int nt0 = blockIdx.y * NT + wn * NTW, N = 32 * a.ntot;
     const int o0 = band * a.band_rows;
     const int orows = a.OH - o0 < a.band_rows ? a.OH - o0 : a.band_rows;
     const int crow0 = S * o0, crows = S * orows;
@@ -381,11 +498,11 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
         const float* src = a.in + (long long)clip * a.H * a.W * CIN;
         const int total = irows * Wb * QP;
         const float inv_wb = 1.0f / float(Wb);
-        float4 v[CNN_X3_UNP];
-        int dst[CNN_X3_UNP];
+        float4 v[UNP];
+        int dst[UNP];
 #pragma unroll
-        for (int u = 0; u < CNN_X3_UNP; ++u) {
-            const int i = tid + u * 256;
+        for (int u = 0; u < UNP; ++u) {
+            const int i = tid + u * THREADS;
             const int q = i & (QP - 1), P = i / QP;
             int rr = int(float(P) * inv_wb);
             rr -= (rr * Wb > P);
@@ -398,7 +515,7 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
                 v[u] = *reinterpret_cast<const float4*>(src + ((long long)iy * a.W + ix) * CIN + 4 * q);
         }
 #pragma unroll
-        for (int u = 0; u < CNN_X3_UNP; ++u)
+        for (int u = 0; u < UNP; ++u)
             if (dst[u] >= 0) {
                 uint2 hi, lo;
                 split4(v[u].x, v[u].y, v[u].z, v[u].w, hi, lo);
@@ -409,11 +526,11 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
     __syncthreads();
 
     const int M = orows * a.OW * (POOL ? 4 : 1);
-    if (wave * MW * 32 >= M) return;               // whole wave beyond the band (no barrier follows)
+    if (wm * MW * 32 >= M) return;                 // whole wave beyond the band (no barrier follows)
     int pix[MW];
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
-        int m = (wave * MW + mt) * 32 + r;
+        int m = (wm * MW + mt) * 32 + r;
         if (m >= M) m = M - 1;
         int y, x;
         if constexpr (POOL) {
@@ -426,19 +543,19 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
         }
         pix[mt] = y * Wb + x;
     }
-    f32x16 acc[MW][NT];
+    f32x16 acc[MW][NTW];
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x16{0};
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x16{0};
 
     const bf16_t* wl = a.wf + (size_t(nt0) * 2) * 512 + lane * 8;
     const size_t wstep = size_t(a.ntot) * 2 * 512;
-    constexpr int D = (NT <= 2) ? 4 : 2;
-    bf16x8 wring[D][NT][2], af[2][MW][2];
-    auto wload = [&](int s, bf16x8 (&dst)[NT][2]) {
+    constexpr int D = (NTW <= 2) ? 4 : 2;
+    bf16x8 wring[D][NTW][2], af[2][MW][2];
+    auto wload = [&](int s, bf16x8 (&dst)[NTW][2]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             dst[nt][0] = *reinterpret_cast<const bf16x8*>(wl + size_t(s) * wstep + size_t(nt) * 1024);
             dst[nt][1] = *reinterpret_cast<const bf16x8*>(wl + size_t(s) * wstep + size_t(nt) * 1024 + 512);
         }
@@ -454,9 +571,9 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) aload(std::integral_constant<int, 0>{}, mt, af[0][mt]);
     auto step = [&]<int s>() {
-        bf16x8 bw[NT][2];
+        bf16x8 bw[NTW][2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bw[nt][0] = wring[s % D][nt][0]; bw[nt][1] = wring[s % D][nt][1]; }
+        for (int nt = 0; nt < NTW; ++nt) { bw[nt][0] = wring[s % D][nt][0]; bw[nt][1] = wring[s % D][nt][1]; }
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
             if constexpr (s + 1 < KSTEPS) aload(std::integral_constant<int, s + 1>{}, mt, af[(s + 1) & 1][mt]);
@@ -465,7 +582,7 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][0], acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][1], bw[nt][0], acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][1], acc[mt][nt], 0, 0, 0);
@@ -481,9 +598,9 @@ __global__ __launch_bounds__(256) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
     float* o = a.out + ((long long)clip * a.OH + o0) * a.OW * N;
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
-        const int m0 = (wave * MW + mt) * 32;
+        const int m0 = (wm * MW + mt) * 32;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int n = (nt0 + nt) * 32 + r;
             const float bn = a.bias[n];
             if constexpr (POOL) {
@@ -607,19 +724,51 @@ int cnn_upload(void** dst, const std::vector<T>& v) {
     return COUGH_OK;
 }
 
-// output rows per workgroup of the split-bf16 LDS-image convolution (0: the layer does not fit, use the f32 kernel):
-// the kernel's tile shape must exist (cin -> cout pairs it is instantiated for), the band's GEMM rows must fit
-// 4 waves x MW tiles and its two bf16 images CNN_X3_UNP x 256 sixteen-byte pieces
-inline int x3_band(const cough_cnn::Layer& l, const CnnShape& s, int in_w) {
+// Tile configuration of the split-bf16 LDS-image convolution per input width (cin): NT 32-channel tiles per workgroup,
+// WM x WN waves, MW 32-row tiles per wave, PIECES = LDS capacity of the band's two images in 16-byte units.
+struct X3Cfg { int nt, mw, wm, wn, pieces; };
+#ifndef CNN_X3_CFG32
+// measured (profiles/r04_cnn_x3_experiments.txt): 4-wave workgroups of 2 x 2 waves with bands small enough for TWO per CU
+// (one's staging overlaps the other's MFMA phase) for the 32- and 64-channel inputs; the 128-channel input (one clip =
+// 120 GEMM rows, 86 KB of images: one workgroup per CU) as 2 x 4 waves so that all eight waves have rows
+#define CNN_X3_CFG32 2, 5, 2, 2, 5056
+#define CNN_X3_CFG64 4, 3, 2, 2, 5056
+#define CNN_X3_CFG128 4, 2, 2, 4, 6144
+#endif
+#define CNN_X3_CFG16 1, 4, 4, 1, 6144
+constexpr X3Cfg X3_C16{CNN_X3_CFG16}, X3_C32{CNN_X3_CFG32}, X3_C64{CNN_X3_CFG64}, X3_C128{CNN_X3_CFG128};
+inline const X3Cfg* x3_cfg(const cough_cnn::Layer& l) {
     const int nt = l.cout >= 128 ? 4 : l.cout / 32;
-    const bool shape_ok = (l.cin == 16 && nt == 1) || (l.cin == 32 && nt == 2) || (l.cin == 64 && nt == 4) ||
-                          (l.cin == 128 && nt == 4);
-    if (!shape_ok) return 0;
-    const int mw = (l.cin == 64 || l.cin == 128) ? 2 : 4, per_out = l.pool == 2 ? 4 : 1;
-    int band = (4 * mw * 32) / (per_out * s.w);
+    if (l.cin == 16 && nt == X3_C16.nt) return &X3_C16;
+    if (l.cin == 32 && nt == X3_C32.nt) return &X3_C32;
+    if (l.cin == 64 && nt == X3_C64.nt) return &X3_C64;
+    if (l.cin == 128 && nt == X3_C128.nt) return &X3_C128;
+    return nullptr;
+}
+// output rows per workgroup (0: the layer does not fit, use the f32 kernel): the kernel's tile shape must exist, the
+// band's GEMM rows must fit WM waves x MW tiles and its two bf16 images the configuration's LDS capacity
+inline int x3_band(const cough_cnn::Layer& l, const CnnShape& s, int in_w) {
+    const X3Cfg* c = x3_cfg(l);
+    if (!c) return 0;
+    const int per_out = l.pool == 2 ? 4 : 1;
+    int band = (c->wm * c->mw * 32) / (per_out * s.w);
     if (band > s.h) band = s.h;
-    while (band >= 1 && size_t((l.pool == 2 ? 2 : 1) * band + 2) * (in_w + 2) * (l.cin / 4) > size_t(CNN_X3_UNP) * 256) --band;
+    while (band >= 1 && size_t((l.pool == 2 ? 2 : 1) * band + 2) * (in_w + 2) * (l.cin / 4) > size_t(c->pieces)) --band;
     return band;
+}
+template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
+void x3_launch(bool pool, dim3 grid, size_t lds, hipStream_t st, const CnnX3Args& a) {
+    if (pool) hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES>), grid, dim3(64 * WM * WN), lds, st, a);
+    else hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES>), grid, dim3(64 * WM * WN), lds, st, a);
+}
+template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
+hipError_t x3_set_lds() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
+    return e;
 }
 
 template <typename T>
@@ -639,7 +788,13 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
         if (i == 0) {
             const long long n_out = (long long)n * s.h * s.w;
             const dim3 grid((unsigned)((n_out + 255) / 256));
-            if (l.pool == 2)
+            const FirstLds fl = first_lds(ch, cw);
+            if (sizeof(T) == 4 && m->dtype == COUGH_DTYPE_BF16X3 && l.d_wfrag && l.pool == 2 && ch * cw <= 2 * 256 * CNN_FIRST_MAXL &&
+                2 * fl.bytes <= 64 * 1024) {
+                if constexpr (sizeof(T) == 4)
+                    hipLaunchKernelGGL(cnn_first_x3_kernel, dim3(n), dim3(256), 2 * fl.bytes, st, d_feat, ch, cw, s.h, s.w, fl.nrows,
+                                       fl.pitch, l.d_wfrag, l.d_b, l.cout, dst);
+            } else if (l.pool == 2)
                 hipLaunchKernelGGL((cnn_first_kernel<T, true>), grid, dim3(256), 0, st, d_feat, ch, cw, s.h, s.w, n_out,
                                    static_cast<const float*>(l.d_w), l.d_b, l.cout, dst);
             else
@@ -694,16 +849,10 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
                 CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32};
                 const int nt = l.cout >= 128 ? 4 : l.cout / 32;
                 const dim3 grid((unsigned)(n * n_bands), (unsigned)(l.cout / (32 * nt)));
-#define COUGH_X3_LAUNCH(CIN, NT, MW)                                                                                 \
-    do {                                                                                                             \
-        if (l.pool == 2) hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, true>), grid, dim3(256), lds, st, a);   \
-        else hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, false>), grid, dim3(256), lds, st, a);              \
-    } while (0)
-                if (l.cin == 16) COUGH_X3_LAUNCH(16, 1, 4);
-                else if (l.cin == 32) COUGH_X3_LAUNCH(32, 2, 4);
-                else if (l.cin == 64) COUGH_X3_LAUNCH(64, 4, 2);
-                else COUGH_X3_LAUNCH(128, 4, 2);
-#undef COUGH_X3_LAUNCH
+                if (l.cin == 16) x3_launch<16, CNN_X3_CFG16>(l.pool == 2, grid, lds, st, a);
+                else if (l.cin == 32) x3_launch<32, CNN_X3_CFG32>(l.pool == 2, grid, lds, st, a);
+                else if (l.cin == 64) x3_launch<64, CNN_X3_CFG64>(l.pool == 2, grid, lds, st, a);
+                else x3_launch<128, CNN_X3_CFG128>(l.pool == 2, grid, lds, st, a);
             }
         } else {
             CnnConvArgs<T> a{};
@@ -868,23 +1017,36 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
                         }
             err = cnn_upload(reinterpret_cast<void**>(&l.d_wfrag), wfr);
         }
+        if (!err && i == 0 && dtype == COUGH_DTYPE_BF16X3 && bk.pool == 2 && N <= 32) {
+            // B fragments of cnn_first_x3_kernel: lane (n, h), element jj <-> k = 8h + jj = 4 kh + kw' (kw' = 3 and kh = 3: zero)
+            std::vector<bf16_t> wfr(2 * 512, 0);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int n = lane & 31, k = 8 * (lane >> 5) + jj, kh = k >> 2, kw = k & 3;
+                    if (n >= N || kh >= 3 || kw >= 3) continue;
+                    const float v = float(wd[size_t(n) * 9 + kh * 3 + kw]);
+                    const bf16_t hi = f2bf_host(v);
+                    const uint32_t hb = uint32_t(hi) << 16;
+                    float hf;
+                    std::memcpy(&hf, &hb, 4);
+                    wfr[size_t(lane) * 8 + jj] = hi;
+                    wfr[512 + size_t(lane) * 8 + jj] = f2bf_host(v - hf);
+                }
+            err = cnn_upload(reinterpret_cast<void**>(&l.d_wfrag), wfr);
+        }
         if (!err) err = cnn_upload(reinterpret_cast<void**>(&l.d_b), bf);
         m->layers.push_back(l);
     }
     m->feat_c = w->blocks[w->n_blocks - 1].cout;
     m->hidden = w->hidden;
     if (!err && dtype == COUGH_DTYPE_BF16X3) {   // the two LDS images of a band can exceed 64 KB
-        const void* fns[] = {
-            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<16, 1, 4, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<16, 1, 4, false>),
-            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<32, 2, 4, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<32, 2, 4, false>),
-            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<64, 4, 2, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<64, 4, 2, false>),
-            reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<128, 4, 2, true>), reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<128, 4, 2, false>)};
-        for (const void* fn : fns) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CNN_X3_UNP * 256 * 16 + 64);
-            if (e != hipSuccess && !err) {
-                set_error("cough_cnn_create: %s", hipGetErrorString(e));
-                err = COUGH_EHIP;
-            }
+        hipError_t e = x3_set_lds<16, CNN_X3_CFG16>();
+        if (e == hipSuccess) e = x3_set_lds<32, CNN_X3_CFG32>();
+        if (e == hipSuccess) e = x3_set_lds<64, CNN_X3_CFG64>();
+        if (e == hipSuccess) e = x3_set_lds<128, CNN_X3_CFG128>();
+        if (e != hipSuccess) {
+            set_error("cough_cnn_create: %s", hipGetErrorString(e));
+            err = COUGH_EHIP;
         }
     }
     if (!err) {   // fc1 transposed to [C][hidden] for coalesced reads in the head kernel
