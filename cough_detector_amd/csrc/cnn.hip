@@ -470,23 +470,13 @@ struct CnnX3Args {
     int band_rows;        // output rows per workgroup
     int n_bands;          // workgroups per clip
     int ntot;             // 32-channel tiles of the layer
-    // FIRST (the network's first two blocks in one kernel): `in` is unused; the band's input is COMPUTED from the feature image
-    const float* feat;    // [B][FH][FW] f32 (one channel); H = FH / 2, W = FW / 2 is the first block's pooled output
-    const bf16_t* wf0;    // first block: B fragments of cnn_first_x3_kernel [2][64][8]
-    const float* bias0;   // [CIN]
-    int FH, FW;
 };
 
 // The workgroup is WM x WN waves: wave (wm, wn) owns MW 32-row tiles x NT / WN 32-channel tiles of the band, so the band
 // image is staged ONCE for all NT tiles while a wave's accumulators are MW * NT / WN * 16 registers (r03: one N-wave, 128
 // AGPRs + 140-156 VGPRs = one wave per SIMD).  PIECES: 16-byte f32 pieces (4 channels of a pixel) the band may hold =
 // LDS bytes of its two images / 16.
-// FIRST: the band's input -- the first block's output (conv 3x3 of the 1-channel feature image + BN + ReLU + 2x2 max, CIN
-// channels) -- is computed HERE, on the matrix cores exactly as cnn_first_x3_kernel does, from a bf16 (hi, lo) copy of the
-// feature rows the band needs, and written (split) straight into the band's two LDS images: the first block's activation
-// (standard: 288 KB per clip, 1.18 GB per launch written and re-read) never exists in HBM.  Same values, same rounding
-// points as the two-kernel chain (f32 result -> hi = bf16(v), lo = bf16(v - hi)): bit-identical outputs.
-template <int CIN, int NT, int MW, bool POOL, int WM, int WN, int PIECES, bool FIRST = false>
+template <int CIN, int NT, int MW, bool POOL, int WM, int WN, int PIECES>
 __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
     constexpr int QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1, THREADS = 64 * WM * WN, NTW = NT / WN;
     constexpr int UNP = (PIECES + THREADS - 1) / THREADS;   // 16-byte pieces per thread
@@ -503,94 +493,6 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
     bf16_t* img = reinterpret_cast<bf16_t*>(smem_raw);                       // hi image
     bf16_t* img_lo = img + ((irows * Wb * CIN + 7) & ~7);                    // lo image (16-byte aligned)
 
-    if constexpr (FIRST) {
-        // ---- the band's input rows crow0 - 1 .. crow0 + crows of the first block's output, computed in place ----
-        static_assert(CIN <= 32, "the first block's channels are one 32-column MFMA tile");
-        const int img_elems = (irows * Wb * CIN + 7) & ~7;
-        bf16_t* fimg = img_lo + img_elems;                                       // feature band, hi image (16-byte aligned)
-        const int FR = 2 * irows + 2, fpitch = (a.FW + 7) & ~1, fplane = FR * fpitch;   // feature rows 2 crow0 - 3 .. (bordered cols)
-        const int f0 = 2 * crow0 - 3;
-        {   // zero both band images and both feature images (borders, rows outside the image)
-            const int n16 = (2 * img_elems + 2 * fplane + 7) / 8;
-            for (int i = tid; i < n16; i += THREADS) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        {
-            const float* src = a.feat + (long long)clip * a.FH * a.FW;
-            const float inv_fw = 1.0f / float(a.FW);
-            for (int e = tid; e < FR * a.FW; e += THREADS) {
-                int fr = __float2int_rz(__int2float_rn(e) * inv_fw);
-                fr -= (fr * a.FW > e);
-                fr += ((fr + 1) * a.FW <= e);
-                const int fc = e - fr * a.FW, grow = f0 + fr;
-                if (grow >= 0 && grow < a.FH) {
-                    const float v = src[grow * a.FW + fc];
-                    const bf16_t hi = f2bf(v);
-                    fimg[fr * fpitch + fc + 1] = hi;
-                    fimg[fplane + fr * fpitch + fc + 1] = f2bf(v - bf2f(hi));
-                }
-            }
-        }
-        const bf16x8 bw_hi = *reinterpret_cast<const bf16x8*>(a.wf0 + lane * 8);
-        const bf16x8 bw_lo = *reinterpret_cast<const bf16x8*>(a.wf0 + 512 + lane * 8);
-        const float bn0 = r < CIN ? a.bias0[r] : 0.f;
-        __syncthreads();
-        // local rows rl of the band image whose first-block row crow0 - 1 + rl exists
-        const int rl_lo = crow0 >= 1 ? 0 : 1 - crow0;
-        const int rl_hi = irows < a.H - crow0 + 1 ? irows : a.H - crow0 + 1;
-        const int n_win = (rl_hi - rl_lo) * a.W, n_tiles = (n_win + 7) / 8;
-        const int q = r >> 2, dy = (r >> 1) & 1, dx = r & 1;
-        const float inv_w1 = 1.0f / float(a.W);
-        auto rowcol = [&](int w, int& rl, int& ca) {
-            rl = __float2int_rz(__int2float_rn(w) * inv_w1);
-            rl -= (rl * a.W > w);
-            rl += ((rl + 1) * a.W <= w);
-            ca = w - rl * a.W;
-            rl += rl_lo;
-        };
-        for (int tile = wave; tile < n_tiles; tile += WM * WN) {
-            int win = tile * 8 + q;
-            if (win >= n_win) win = n_win - 1;
-            int rl, ca;
-            rowcol(win, rl, ca);
-            const int x = 2 * ca + dx;
-            const int rowA = 2 * rl + dy + 2 * h, rowB = h ? rowA : rowA + 1;   // bordered feature band rows of kernel rows 0 / 1 (h = 0), 2 (h = 1)
-            const int cb = x & ~1;
-            const unsigned sh = 2u * unsigned(x & 1);
-            const uint32_t* pa = reinterpret_cast<const uint32_t*>(fimg + rowA * fpitch + cb);
-            const uint32_t* pb = reinterpret_cast<const uint32_t*>(fimg + rowB * fpitch + cb);
-            union { uint32_t u[4]; bf16x8 v; } ah, al;
-            {
-                const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-                ah.u[0] = __builtin_amdgcn_alignbyte(a1, a0, sh); ah.u[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                ah.u[2] = __builtin_amdgcn_alignbyte(b1, b0, sh); ah.u[3] = __builtin_amdgcn_alignbyte(b2, b1, sh);
-            }
-            {
-                const uint32_t* qa = pa + fplane / 2;
-                const uint32_t* qb = pb + fplane / 2;
-                const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
-                al.u[0] = __builtin_amdgcn_alignbyte(a1, a0, sh); al.u[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                al.u[2] = __builtin_amdgcn_alignbyte(b1, b0, sh); al.u[3] = __builtin_amdgcn_alignbyte(b2, b1, sh);
-            }
-            f32x16 acc0 = {0};
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bw_hi, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bw_hi, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bw_lo, acc0, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int wo = tile * 8 + 2 * g + h;
-                const float v = fmaxf(fmaxf(fmaxf(acc0[4 * g], acc0[4 * g + 1]), fmaxf(acc0[4 * g + 2], acc0[4 * g + 3])) + bn0, 0.f);
-                if (wo < n_win && r < CIN) {
-                    int orl, oca;
-                    rowcol(wo, orl, oca);
-                    const int off = swz_off<CIN>(orl * Wb + oca + 1, r >> 3) + (r & 7);
-                    const bf16_t hi = f2bf(v);
-                    img[off] = hi;
-                    img_lo[off] = f2bf(v - bf2f(hi));
-                }
-            }
-        }
-    } else {
     // ---- stage: every 16-byte f32 piece (4 channels of one pixel) is requested before the first one is split ----
     {
         const float* src = a.in + (long long)clip * a.H * a.W * CIN;
@@ -620,7 +522,6 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
                 *reinterpret_cast<uint2*>(img + dst[u]) = hi;
                 *reinterpret_cast<uint2*>(img_lo + dst[u]) = lo;
             }
-    }
     }
     __syncthreads();
 
@@ -861,21 +762,6 @@ void x3_launch(bool pool, dim3 grid, size_t lds, hipStream_t st, const CnnX3Args
     else hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES>), grid, dim3(64 * WM * WN), lds, st, a);
 }
 template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
-void x3_launch_first(bool pool, dim3 grid, size_t lds, hipStream_t st, const CnnX3Args& a) {
-    if (pool) hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES, true>), grid, dim3(64 * WM * WN), lds, st, a);
-    else hipLaunchKernelGGL((cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES, true>), grid, dim3(64 * WM * WN), lds, st, a);
-}
-constexpr size_t X3_FIRST_EXTRA = 24 * 1024;   // LDS the fused first block's feature band may add to the band images
-template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
-hipError_t x3_set_lds_first() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(PIECES * 16 + 64 + X3_FIRST_EXTRA));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(PIECES * 16 + 64 + X3_FIRST_EXTRA));
-    return e;
-}
-template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
 hipError_t x3_set_lds() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
@@ -883,19 +769,6 @@ hipError_t x3_set_lds() {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
     return e;
-}
-
-// > 0 (the extra LDS bytes of the feature band): blocks 0 and 1 run as one kernel -- split-bf16 mode, a pooled first block of
-// 16 or 32 channels with fragments, a second block the band kernel takes, nobody taps block 0's output, and one grid.y
-inline size_t x3_fuse_first(const cough_cnn* m, const std::vector<CnnShape>& shp, int H, int W, int tap_layer, const float* d_tap) {
-    if (m->dtype != COUGH_DTYPE_BF16X3 || m->layers.size() < 2 || (d_tap && tap_layer == 0)) return 0;
-    const auto &l0 = m->layers[0], &l1 = m->layers[1];
-    if (!l0.d_wfrag || l0.pool != 2 || !l1.d_wfrag || (l1.cin != 16 && l1.cin != 32) || l1.cout > 128) return 0;
-    const int band = x3_band(l1, shp[1], shp[0].w);
-    if (band < 1) return 0;
-    const int irows = (l1.pool == 2 ? 2 : 1) * band + 2, fr = 2 * irows + 2, fpitch = (W + 7) & ~1;
-    const size_t extra = (size_t(fr) * fpitch * 2 * 2 + 15) / 16 * 16 + 16;
-    return extra <= X3_FIRST_EXTRA ? extra : 0;
 }
 
 template <typename T>
@@ -912,9 +785,7 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
         const auto& l = m->layers[i];
         const CnnShape& s = shp[i];
         T* dst = ping[i & 1];
-        if (i == 0 && x3_fuse_first(m, shp, H, W, tap_layer, d_tap) > 0) {
-            // the first two blocks run as ONE kernel (cnn_conv_lds_x3_kernel<..., FIRST>): nothing to launch for block 0
-        } else if (i == 0) {
+        if (i == 0) {
             const long long n_out = (long long)n * s.h * s.w;
             const dim3 grid((unsigned)((n_out + 255) / 256));
             const FirstLds fl = first_lds(ch, cw);
@@ -975,16 +846,10 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
                 // and as two band images of <= 96 KB hold
                 const int band = x3_band(l, s, cw), n_bands = (s.h + band - 1) / band;
                 const size_t lds = (size_t((l.pool == 2 ? 2 : 1) * band + 2) * (cw + 2) * l.cin * 2 + 15) / 16 * 16 * 2;
-                CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32, nullptr, nullptr, nullptr, 0, 0};
+                CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32};
                 const int nt = l.cout >= 128 ? 4 : l.cout / 32;
                 const dim3 grid((unsigned)(n * n_bands), (unsigned)(l.cout / (32 * nt)));
-                const size_t fuse_extra = i == 1 ? x3_fuse_first(m, shp, H, W, tap_layer, d_tap) : 0;
-                if (fuse_extra > 0) {
-                    a.in = nullptr;
-                    a.feat = d_feat; a.wf0 = m->layers[0].d_wfrag; a.bias0 = m->layers[0].d_b; a.FH = H; a.FW = W;
-                    if (l.cin == 16) x3_launch_first<16, CNN_X3_CFG16>(l.pool == 2, grid, lds + fuse_extra, st, a);
-                    else x3_launch_first<32, CNN_X3_CFG32>(l.pool == 2, grid, lds + fuse_extra, st, a);
-                } else if (l.cin == 16) x3_launch<16, CNN_X3_CFG16>(l.pool == 2, grid, lds, st, a);
+                if (l.cin == 16) x3_launch<16, CNN_X3_CFG16>(l.pool == 2, grid, lds, st, a);
                 else if (l.cin == 32) x3_launch<32, CNN_X3_CFG32>(l.pool == 2, grid, lds, st, a);
                 else if (l.cin == 64) x3_launch<64, CNN_X3_CFG64>(l.pool == 2, grid, lds, st, a);
                 else x3_launch<128, CNN_X3_CFG128>(l.pool == 2, grid, lds, st, a);
@@ -1176,8 +1041,6 @@ extern "C" int cough_cnn_create(cough_cnn** out, const cough_cnn_weights* w, int
     m->hidden = w->hidden;
     if (!err && dtype == COUGH_DTYPE_BF16X3) {   // the two LDS images of a band can exceed 64 KB
         hipError_t e = x3_set_lds<16, CNN_X3_CFG16>();
-        if (e == hipSuccess) e = x3_set_lds_first<16, CNN_X3_CFG16>();
-        if (e == hipSuccess) e = x3_set_lds_first<32, CNN_X3_CFG32>();
         if (e == hipSuccess) e = x3_set_lds<32, CNN_X3_CFG32>();
         if (e == hipSuccess) e = x3_set_lds<64, CNN_X3_CFG64>();
         if (e == hipSuccess) e = x3_set_lds<128, CNN_X3_CFG128>();
