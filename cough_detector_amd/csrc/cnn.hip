@@ -470,6 +470,9 @@ struct CnnX3Args {
     int band_rows;        // output rows per workgroup
     int n_bands;          // workgroups per clip
     int ntot;             // 32-channel tiles of the layer
+    float* mean_out;      // last block, one band per clip: [B][32 * ntot] channel means over OH x OW (the head's global
+                          // average pool, model.py:118-121 / :198-200) INSTEAD of `out` -- the activation is neither written
+                          // nor re-read by the head kernel.  nullptr: store `out`
 };
 
 // The workgroup is WM x WN waves: wave (wm, wn) owns MW 32-row tiles x NT / WN 32-channel tiles of the band, so the band
@@ -526,7 +529,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
     __syncthreads();
 
     const int M = orows * a.OW * (POOL ? 4 : 1);
-    if (wm * MW * 32 >= M) return;                 // whole wave beyond the band (no barrier follows)
+    if (wm * MW * 32 >= M && a.mean_out == nullptr) return;   // whole wave beyond the band (no barrier follows; the fused
+                                                               // mean has two: there such a wave computes masked rows)
     int pix[MW];
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
@@ -596,6 +600,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
 
     // epilogue: register `reg` of lane (r, h) is GEMM row (reg & 3) + 8 * (reg >> 2) + 4 * h of the tile, column r
     float* o = a.out + ((long long)clip * a.OH + o0) * a.OW * N;
+    const bool to_mean = a.mean_out != nullptr;   // workgroup-uniform
+    float csum[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) csum[nt] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
         const int m0 = (wm * MW + mt) * 32;
@@ -607,17 +615,42 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int win = (m0 >> 2) + 2 * g + h;
-                    const float v = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]),
-                                          fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
-                    if (win * 4 < M) o[(long long)win * N + n] = fmaxf(v + bn, 0.f);
+                    const float v = fmaxf(fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]),
+                                                fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3])) + bn, 0.f);
+                    if (win * 4 < M) {
+                        if (to_mean) csum[nt] += v;
+                        else o[(long long)win * N + n] = v;
+                    }
                 }
             } else {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int mo = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    if (mo < M) o[(long long)mo * N + n] = fmaxf(acc[mt][nt][reg] + bn, 0.f);
+                    const float v = fmaxf(acc[mt][nt][reg] + bn, 0.f);
+                    if (mo < M) {
+                        if (to_mean) csum[nt] += v;
+                        else o[(long long)mo * N + n] = v;
+                    }
                 }
             }
+        }
+    }
+    if (to_mean) {
+        // channel means of the clip (one band = the whole image): lane rows, then the two lane halves, then the M-waves, in
+        // that fixed order -- deterministic and independent of the batch
+        __syncthreads();                                   // every wave has finished reading the images
+        float* red = reinterpret_cast<float*>(smem_raw);   // [WM][NT * 32]
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const float t = csum[nt] + __shfl_xor(csum[nt], 32, 64);
+            if (h == 0) red[wm * (NT * 32) + (wn * NTW + nt) * 32 + r] = t;
+        }
+        __syncthreads();
+        if (tid < NT * 32) {
+            float t = red[tid];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) t += red[w * (NT * 32) + tid];
+            a.mean_out[(long long)clip * N + blockIdx.y * (NT * 32) + tid] = t / float(a.OH * a.OW);
         }
     }
 }
@@ -781,6 +814,7 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
     T* ping[2] = {reinterpret_cast<T*>(ws), reinterpret_cast<T*>(ws + buf)};
     const T* cur = nullptr;
     int ch = H, cw = W;
+    bool means_in_dst = false;
     for (size_t i = 0; i < m->layers.size(); ++i) {
         const auto& l = m->layers[i];
         const CnnShape& s = shp[i];
@@ -846,7 +880,13 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
                 // and as two band images of <= 96 KB hold
                 const int band = x3_band(l, s, cw), n_bands = (s.h + band - 1) / band;
                 const size_t lds = (size_t((l.pool == 2 ? 2 : 1) * band + 2) * (cw + 2) * l.cin * 2 + 15) / 16 * 16 * 2;
-                CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32};
+                CnnX3Args a{cur, l.d_wfrag, l.d_b, dst, ch, cw, s.h, s.w, band, n_bands, l.cout / 32, nullptr};
+                // last block, whole image in one band, logits wanted, nobody taps the activation: its epilogue forms the
+                // head's channel means ([n][cout] floats in `dst`) and the activation never crosses HBM
+                if (i + 1 == m->layers.size() && n_bands == 1 && d_logits && !(d_tap && tap_layer == int(i))) {
+                    a.mean_out = reinterpret_cast<float*>(dst);
+                    means_in_dst = true;
+                }
                 const int nt = l.cout >= 128 ? 4 : l.cout / 32;
                 const dim3 grid((unsigned)(n * n_bands), (unsigned)(l.cout / (32 * nt)));
                 if (l.cin == 16) x3_launch<16, CNN_X3_CFG16>(l.pool == 2, grid, lds, st, a);
@@ -884,8 +924,9 @@ int cnn_forward_impl(const cough_cnn* m, const float* d_feat, int n, int H, int 
         cw = s.w;
     }
     if (d_logits) {
-        hipLaunchKernelGGL(cnn_tail_kernel<T>, dim3(n), dim3(256), 0, st, cur, ch * cw, m->feat_c, m->hidden, m->d_w1,
-                           m->d_b1, m->d_w2, m->d_b2, d_logits, d_probs, d_preds);
+        // (means_in_dst: `cur` holds the channel means, i.e. a 1 x 1 "image" per clip)
+        hipLaunchKernelGGL(cnn_tail_kernel<T>, dim3(n), dim3(256), 0, st, cur, means_in_dst ? 1 : ch * cw, m->feat_c, m->hidden,
+                           m->d_w1, m->d_b1, m->d_w2, m->d_b2, d_logits, d_probs, d_preds);
         COUGH_HIP_CHECK(hipGetLastError());
     }
     return COUGH_OK;
