@@ -66,7 +66,7 @@ def measured_pmc(batch: int, variant: str) -> dict:
     collected from inside this process, so the figures are read from profiles/ and only used when the batch matches.
     ``variant``: "k1" (featurise alone), "k1_fused_bf16_approx" or "k1_fused_bf16x3"."""
     names = {"k1": ["r01_k1_pmc.json"], "k1_fused_bf16_approx": ["r01_k1_fused_pmc.json"],
-             "k1_fused_bf16x3": ["r03_k1_fused_x3_pmc.json", "r02_k1_fused_x3_pmc.json"]}[variant]
+             "k1_fused_bf16x3": ["r04_k1_fused_x3_pmc.json", "r03_k1_fused_x3_pmc.json", "r02_k1_fused_x3_pmc.json"]}[variant]
     for name in names:                                   # newest record first
         path = os.path.join(ROOT, "profiles", name)
         try:
@@ -99,13 +99,15 @@ def stft_stage(pre, batches, launches: int = 210) -> dict:
     ms = e0.elapsed_time(e1) / launches
     achieved = b * BYTES_PER_CLIP_STFT / (ms * 1e-3) / 1e9
     traffic, src = None, None
-    try:                                                  # committed rocprofv3 PMC record of the same kernel
-        with open(os.path.join(ROOT, "profiles", "r03_stft_pmc.json")) as f:
-            p = json.load(f)
-        if p["clips_per_launch"] == b:
-            traffic, src = int(p["traffic_bytes_per_launch"]), "profiles/r03_stft_pmc.json"
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r04_stft_pmc.json", "r03_stft_pmc.json"):   # committed rocprofv3 PMC record of the same kernel, newest first
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                p = json.load(f)
+            if p["clips_per_launch"] == b:
+                traffic, src = int(p["traffic_bytes_per_launch"]), "profiles/" + name
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     return {"kernel": "stft3_kernel (waveform -> 257x101 power spectrogram; persistent, one 13-wave workgroup per CU)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),

@@ -54,5 +54,5 @@ for _ in range(args.rounds):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.launches
-    print(f"stft B={B} {os.environ.get('COUGH_AMD_LIB', 'lib').split('/')[-1]} v1={os.environ.get('COUGH_STFT_V1')}: {ms:.4f} ms/launch  "
+    print(f"stft B={B} {os.environ.get('COUGH_AMD_LIB', 'lib').split('/')[-1]}: {ms:.4f} ms/launch  "
           f"{nbytes / ms / 1e6:.1f} GB/s algorithmic  ({nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)

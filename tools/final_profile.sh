@@ -2,7 +2,7 @@
 # Round-end measurement batch on the GPU box: benches, rocprofv3 kernel stats, PMC passes.  Outputs under gpurun_out/<tag>/.
 # Usage: bash tools/final_profile.sh <tag>
 set -u
-TAG=${1:-r03/final}
+TAG=${1:-r04/final}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -24,4 +24,6 @@ python tools/pmc_agg.py $OUT/pmc_all "featurize_kernel" > $OUT/pmc_k1_fused_x3_s
 python tools/pmc_to_json.py $OUT/pmc_all $OUT/k1_fused_x3_pmc.json 4096 featurize 100360 > $OUT/k1_fused_x3_pmc.txt && \
 bash tools/pmc_kernel.sh $TAG/pmc_stft "stft3_kernel" tools/bench_stft.py --launches 6 --rounds 1 --prewarm-s 0 > $OUT/pmc_stft.txt 2>&1 && \
 python tools/pmc_to_json.py $OUT/pmc_stft $OUT/stft_pmc.json 4096 stft3 167828 > $OUT/stft_pmc.txt && \
+python tools/bench_models.py > $OUT/bench_models.txt 2>&1 && python tools/bench_models.py --dtypes bf16x3 --iters 20 >> $OUT/bench_models.txt 2>&1 && \
+python tools/bench_heights.py > $OUT/bench_heights.txt 2>&1 && \
 echo FINAL_PROFILE_OK
