@@ -17,8 +17,8 @@
  *     their immutable tables (window, twiddles, sparse filterbank, DCT, folded
  *     and packed conv weights);
  *   - handles are immutable after creation: any number of host threads may launch
- *     with the same handle (reference threading: one consumer thread,
- *     /root/reference/src/inference.py:302-335).
+ *     with the same handle, each with its own workspace and stream (reference threading: one
+ *     consumer thread, /root/reference/src/inference.py:302-335; tests/test_gpu_threads.py).
  */
 #ifndef COUGH_AMD_H
 #define COUGH_AMD_H
@@ -44,8 +44,15 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
 /* ------------------------------------------------------------------ featuriser (K1)
  * Replaces AudioPreprocessor.__init__ / extract_features / normalize
  * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for every flag of the
- * constructor (the shipped set is /root/reference/src/train.py:264-287) at the STFT geometry
- * given below.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
+ * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry at
+ * n_fft = 512: any sample_rate, hop_length >= 1, win_length <= 512, n_mels <= 128, n_mfcc <= n_mels,
+ * any filterbank (f_min / f_max), any segment longer than 256 samples (RealtimePreprocessor's
+ * window_duration, :559-580; the engine's re-construction from a checkpoint config,
+ * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry,
+ * which (with a filterbank of <= 8 taps per band below bin 128, i.e. f_max <= sample_rate / 4) runs on
+ * the tuned one-launch kernel; every other geometry runs on a chain of small kernels and NEEDS A
+ * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft != 512 returns
+ * COUGH_EUNSUPPORTED.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
  * (log-mel or PCEN), MFCC, delta, (delta-delta), (spectral contrast + centroid). */
 #define COUGH_MAX_CONTRAST_BANDS 16
 typedef struct cough_feat_config {
@@ -82,13 +89,15 @@ int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_ti
 
 #define COUGH_FEAT_NORMALIZE 1 /* apply normalize() (peak, per clip) before extract_features */
 
-/* d_wav: n_clips rows of segment_samples float32, row i at d_wav + i*wav_stride (elements,
- * multiple of 4, base 16-byte aligned).  d_feat: [n_clips][num_features][num_frames] float32.
+/* d_wav: n_clips rows of segment_samples float32, row i at d_wav + i*wav_stride (elements; for the
+ * shipped geometry a multiple of 4 with a 16-byte aligned base, otherwise any stride >= segment_samples).
+ * d_feat: [n_clips][num_features][num_frames] float32, num_frames = segment_samples / hop_length + 1.
  * All reductions (peak, top_db floor, MFCC mean/std) are per clip. */
 int cough_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                     float* d_feat, int n_clips, int flags, void* stream);
 
-/* Same, for configurations that need scratch memory (use_spectral_contrast: two spectrograms of a sub-batch).
+/* Same, for configurations that need scratch memory (use_spectral_contrast: two spectrograms of a sub-batch;
+ * any non-shipped geometry: the power spectrogram and the mel powers of a sub-batch, <= 192 MiB).
  * cough_featurizer_workspace_bytes is 0 for every other configuration, and cough_featurize then equals
  * cough_featurize_ws(..., NULL, 0, ...); cough_featurize on a configuration that needs scratch returns
  * COUGH_EWORKSPACE.  d_workspace: device memory, 256-byte aligned, owned by the caller. */
@@ -96,9 +105,10 @@ size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
 int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,
                        int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Stand-alone STFT: T.Spectrogram(n_fft=512, win_length=400, hop_length=160, power=2.0) of
+/* Stand-alone STFT: T.Spectrogram(n_fft=512, win_length, hop_length, power=2.0) of
  * /root/reference/src/preprocessing.py:131-136 (the "STFT stage" on its own; cough_featurize never
- * materialises it).  d_spec: [n_clips][n_fft/2+1 = 257][num_frames = 101] float32.
+ * materialises it) at the featuriser's geometry.  d_spec: [n_clips][n_fft/2+1 = 257][num_frames] float32
+ * (shipped: 101 frames, the persistent kernel the 50 % HBM figure is quoted on).
  * flags: COUGH_SPEC_MAGNITUDE -> power=1.0; COUGH_SPEC_FULL_WINDOW -> periodic Hann(n_fft) instead of the
  * featuriser's window (both together = the spectrogram T.SpectralCentroid(sample_rate, n_fft, hop_length)
  * forms internally, :137-141). */
@@ -144,7 +154,11 @@ typedef struct cough_resnet_weights {
 typedef struct cough_resnet cough_resnet;
 
 int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype);
-/* The same for any `channels` tuple of CoughDetectorResidual.__init__ (/root/reference/src/model.py:216-247):
+/* The fused split-bf16 kernels of cough_resnet_create are compiled for the feature images the reference's own flags
+ * produce at 101 frames: 90 rows (shipped), 103 rows (constructor defaults: delta-delta) and 110 rows (+ spectral
+ * contrast / centroid); any other image size runs the exact-f32 kernels (same entry points, same results or better).
+ *
+ * The same for any `channels` tuple of CoughDetectorResidual.__init__ (/root/reference/src/model.py:216-247):
  * channels[0 .. n_blocks] = (stem out, block 0 out, ..., block n_blocks-1 out); blocks[i] holds res_blocks.i;
  * fc_w is fc.2.weight [2][channels[n_blocks]].  A model created here ALWAYS runs on the exact-f32 kernels, whatever
  * `dtype` asks for (channel counts padded to multiples of 32 in device memory); the fused split-bf16 / bf16 kernels

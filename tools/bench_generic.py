@@ -1,0 +1,40 @@
+"""Throughput of the generic-geometry featuriser chain (csrc/featurize_generic.hip) next to the tuned kernel.
+Run on the GPU box: python tools/bench_generic.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cough_detector_amd as cda
+from cough_detector_amd.hostcpu import bound_torch_threads
+
+bound_torch_threads()
+SHIPPED = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
+         ("f_max = 8000 Hz (dense bands up to bin 256)", dict(f_max=8000.0), 4096),
+         ("80 mel / 20 MFCC / f_max 8000", dict(n_mels=80, n_mfcc=20, f_max=8000.0), 4096),
+         ("2 s windows (201 frames)", dict(segment_duration=2.0), 2048),
+         ("0.5 s windows (51 frames)", dict(segment_duration=0.5), 8192),
+         ("22.05 kHz, hop 220, win 441", dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441), 4096),
+         ("2 s, all constructor defaults but 4 contrast bands", dict(segment_duration=2.0, use_pcen=True, use_pre_emphasis=True,
+                                                                    use_delta_delta=True, use_spectral_contrast=True,
+                                                                    n_contrast_bands=4), 2048)]
+for name, kw, b in CASES:
+    flags = {**SHIPPED, **{k: v for k, v in kw.items() if k.startswith("use_") or k == "n_contrast_bands"}}
+    geom = {k: v for k, v in kw.items() if k not in flags}
+    pre = cda.AudioPreprocessor(device="cuda", **geom, **flags)
+    w = [torch.randn(b, pre.segment_samples, device="cuda") * 0.1 for _ in range(2)]
+    out = torch.empty((b, pre.get_num_features(), pre.get_expected_time_frames()), device="cuda")
+    for i in range(5):
+        pre.featurize_batch(w[i % 2], normalize=True, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(20):
+        pre.featurize_batch(w[i % 2], normalize=True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    sec = b * pre.segment_samples / pre.sample_rate
+    print(f"{name:55s} B {b:5d}  {tuple(out.shape[1:])}  {ms:8.3f} ms  {b / ms / 1e3:7.2f} M clips/s  "
+          f"{sec / ms * 1e3 / 3600:9.1f} audio-hours/s", flush=True)
