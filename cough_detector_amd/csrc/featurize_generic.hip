@@ -13,8 +13,9 @@
 //   gen_peak       per-clip max |x|                                         (normalize(), :199-212; only when asked)
 //   gen_stft       16 frames per workgroup, the featuriser's 256-point complex FFT (fft256.h) with all 257 bins formed;
 //                  samples are normalised (x / peak) and pre-emphasised (:214-240) as they are loaded; reflect padding of
-//                  torch.stft(center=True)                                  -> P [clip][257][T]   (T.MelSpectrogram's STFT)
-//   gen_mel        mel projection with a CSR filterbank (bands of any width) -> melpow [clip][n_mels][T]
+//                  torch.stft(center=True); <MEL>: the mel projection with a CSR filterbank (bands of any width) runs on
+//                  the tile of powers in LDS                                -> melpow [clip][n_mels][T]
+//                  (without MEL: the spectrogram [clip][257][T] itself -- cough_spectrogram, the contrast rows)
 //   gen_dbstat     per-clip max dB (AmplitudeToDB's top_db floor is per clip), PCEN min / max
 //   gen_rows       mel rows (log-mel :405-410 or PCEN :305-340, :400-404) and the raw MFCC rows (DCT of the floored dB)
 //   gen_zscore     (x - mean) / (std + 1e-8) over a block of rows, unbiased std (:428, :300)
@@ -67,11 +68,18 @@ __global__ __launch_bounds__(256) void gen_peak_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------ STFT
 // One workgroup = 16 consecutive frames of one clip; 16 lanes per frame, as in featurize.hip / spectrogram.hip.
-template <bool MAG>
+// MEL: the mel projection (CSR filterbank) runs here, out of the tile of powers in LDS, and `out` receives the mel powers
+// [clip][n_mels][T] -- the 257-row spectrogram (103 KB per 101 frames) is then neither written nor re-read.
+struct GenMel {
+    int n_mels;
+    const int *lo, *hi, *off;
+    const float* w;
+};
+template <bool MAG, bool MEL>
 __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
                                                        const float2* __restrict__ tw512, const float* __restrict__ peaks,
-                                                       int pre_emph, float coef, float* __restrict__ out) {
+                                                       int pre_emph, float coef, float* __restrict__ out, GenMel mel) {
     __shared__ float xs[4 * 4 * G_XFRAME];
     __shared__ float otile[G_NFREQ * (G_FPB + 1)];
     __shared__ float2 twl[16 * G_XROW];
@@ -146,31 +154,23 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     }
     if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
     __syncthreads();
-    float* o = out + clip * (long long)G_NFREQ * T;
-    for (int idx = tid; idx < G_NFREQ * G_FPB; idx += 256) {
-        const int k = idx >> 4, f = idx & 15, tt = blockIdx.x * G_FPB + f;
-        if (tt < T) o[(long long)k * T + tt] = otile[k * (G_FPB + 1) + f];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ mel projection
-// lane = frame, wave = band (mod 4): the band's bin range and taps are wave-uniform (scalar loads), the spectrogram reads
-// are coalesced along time.
-__global__ __launch_bounds__(256) void gen_mel_kernel(const float* __restrict__ P, int T, int n_mels,
-                                                      const int* __restrict__ lo, const int* __restrict__ hi,
-                                                      const int* __restrict__ off, const float* __restrict__ w,
-                                                      float* __restrict__ melpow) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long clip = blockIdx.y;
-    const int t = blockIdx.x * G_TT + lane;
-    const float* Pc = P + clip * (long long)G_NFREQ * T;
-    for (int m = wave; m < n_mels; m += 4) {
-        const int l = lo[m], h = hi[m];
-        const float* wm = w + off[m];
-        float acc = 0.f;
-        if (t < T)
-            for (int k = l; k < h; ++k) acc = fmaf(wm[k - l], Pc[(long long)k * T + t], acc);
-        if (t < T) melpow[(clip * n_mels + m) * (long long)T + t] = acc;
+    if constexpr (MEL) {
+        // thread = (frame f of the tile, band m mod 16): bins of a band in ascending order
+        const int f = tid & 15, tt = blockIdx.x * G_FPB + f;
+        float* o = out + clip * (long long)mel.n_mels * T;
+        for (int m = tid >> 4; m < mel.n_mels; m += 16) {
+            const int l = mel.lo[m], hb = mel.hi[m];
+            const float* wm = mel.w + mel.off[m];
+            float acc = 0.f;
+            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], otile[k * (G_FPB + 1) + f], acc);
+            if (tt < T) o[(long long)m * T + tt] = acc;
+        }
+    } else {
+        float* o = out + clip * (long long)G_NFREQ * T;
+        for (int idx = tid; idx < G_NFREQ * G_FPB; idx += 256) {
+            const int k = idx >> 4, f = idx & 15, tt = blockIdx.x * G_FPB + f;
+            if (tt < T) o[(long long)k * T + tt] = otile[k * (G_FPB + 1) + f];
+        }
     }
 }
 
@@ -469,7 +469,7 @@ struct GenCarve {
 GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
     GenCarve c;
     const size_t spec = size_t(G_NFREQ) * g->T * 4, mel = size_t(g->n_mels) * g->T * 4;
-    const size_t per = spec * (contrast ? 2 : 1) + mel;
+    const size_t per = spec * (contrast ? 2 : 0) + mel;   // the spectrograms exist only for the contrast rows
     size_t sub = G_SUB_BYTES / per;
     if (sub < 1) sub = 1;
     if (sub > 32768) sub = 32768;   // grid.y
@@ -478,7 +478,7 @@ GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
     c.o_peaks = 0;
     c.o_stat = c.o_peaks + align256g(sub * 4);
     c.o_P = c.o_stat + align256g(sub * 16);
-    c.o_M = c.o_P + align256g(sub * spec);
+    c.o_M = c.o_P + (contrast ? align256g(sub * spec) : 0);
     c.o_mel = c.o_M + (contrast ? align256g(sub * spec) : 0);
     c.total = c.o_mel + align256g(sub * mel);
     return c;
@@ -495,12 +495,13 @@ int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, 
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const dim3 grid((g->T + G_FPB - 1) / G_FPB, n_clips), block(256);
     const float* win = full ? g->win_full : g->win;
+    const GenMel none{0, nullptr, nullptr, nullptr, nullptr};
     if (mag)
-        hipLaunchKernelGGL(gen_stft_kernel<true>, grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win, g->tw256,
-                           g->tw512, (const float*)nullptr, 0, 0.f, d_spec);
+        hipLaunchKernelGGL((gen_stft_kernel<true, false>), grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win,
+                           g->tw256, g->tw512, (const float*)nullptr, 0, 0.f, d_spec, none);
     else
-        hipLaunchKernelGGL(gen_stft_kernel<false>, grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win, g->tw256,
-                           g->tw512, (const float*)nullptr, 0, 0.f, d_spec);
+        hipLaunchKernelGGL((gen_stft_kernel<false, false>), grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win,
+                           g->tw256, g->tw512, (const float*)nullptr, 0, 0.f, d_spec, none);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
@@ -529,9 +530,10 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         const float* pk = normalize ? peaks : nullptr;
         if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, g->N, peaks);
         const dim3 gs((T + G_FPB - 1) / G_FPB, nc), gt((T + G_TT - 1) / G_TT, nc);
-        hipLaunchKernelGGL(gen_stft_kernel<false>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win, g->tw256,
-                           g->tw512, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, P);
-        hipLaunchKernelGGL(gen_mel_kernel, gt, dim3(256), 0, stream, P, T, n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, mel);
+        // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
+        const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w}, none{0, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL((gen_stft_kernel<false, true>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
+                           g->tw256, g->tw512, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
         hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
                            g->dct_t, feat, nfeat);
@@ -541,12 +543,11 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
                                n_mfcc, cfg.use_delta_delta);
         }
         if (want_contrast) {
-            // from the un-emphasised (normalised) signal (:476-478): the power spectrogram above serves when no pre-emphasis ran
-            if (cfg.use_pre_emphasis)
-                hipLaunchKernelGGL(gen_stft_kernel<false>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
-                                   g->tw256, g->tw512, pk, 0, 0.f, P);
-            hipLaunchKernelGGL(gen_stft_kernel<true>, gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win_full,
-                               g->tw256, g->tw512, pk, 0, 0.f, M);
+            // from the un-emphasised (normalised) signal (:476-478)
+            hipLaunchKernelGGL((gen_stft_kernel<false, false>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
+                               g->tw256, g->tw512, pk, 0, 0.f, P, none);
+            hipLaunchKernelGGL((gen_stft_kernel<true, false>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T,
+                               g->win_full, g->tw256, g->tw512, pk, 0, 0.f, M, none);
             hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, contrast, g->freqs,
                                float(g->sample_rate) / 2.0f, feat, nfeat, nbase);
             hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
