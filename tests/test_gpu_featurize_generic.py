@@ -146,3 +146,20 @@ def test_geometry_errors_match_what_torch_would_refuse():
     with pytest.raises(ValueError, match="reflect"):
         cda.AudioPreprocessor(segment_duration=0.01, **SHIPPED)
     assert cda.AudioPreprocessor(n_mels=20, n_mfcc=30, **{**SHIPPED, "use_mfcc": False}).get_num_features() == 20
+
+
+@pytest.mark.parametrize("geom,n", [(dict(segment_duration=5.0), 80000),                       # 501 frames: no LDS cap on T
+                                    (dict(hop_length=600, segment_duration=0.3), 4800),         # hop > n_fft: frames do not overlap
+                                    (dict(hop_length=400, segment_duration=0.02), 320),         # N < hop: ONE frame, mostly reflect padding
+                                    (dict(win_length=1, segment_duration=0.25), 4000)])         # a one-tap window
+def test_extreme_geometries(geom, n):
+    g, seconds = _split(geom)
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **g, **SHIPPED)
+    assert pre.segment_samples == n
+    w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in (0, 3, 4)]))
+    f = pre.featurize_batch(w.cuda(), normalize=True)
+    ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g))
+    assert f.shape == ref.shape == (3, 90, 1 + n // g["hop_length"])
+    mel, rel = errors(f, ref, 64)
+    print(f"{geom}: {tuple(f.shape)} mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < 2 * FEAT_TOL          # (a 13-value z-score of one frame amplifies the dB error by 1 / std)
