@@ -163,3 +163,31 @@ def test_extreme_geometries(geom, n):
     mel, rel = errors(f, ref, 64)
     print(f"{geom}: {tuple(f.shape)} mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
     assert mel < FEAT_TOL and rel < 2 * FEAT_TOL          # (a 13-value z-score of one frame amplifies the dB error by 1 / std)
+
+
+def test_multi_stream_detector_with_two_second_windows_and_hip_graphs():
+    """configs[4]'s streaming engine on a generic geometry: 2 s windows / 0.25 s hop, the captured-graph steady state
+    included (the generic kernel chain is launch-only: no allocation, no synchronisation inside the capture)."""
+    from cough_detector_amd.streaming import MultiStreamDetector
+    from parity import realistic_state_dict
+    sd = realistic_state_dict(11)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="fp32")
+    model.load_state_dict(sd)
+    S = 4
+    now = {"t": 0.0}
+    det = MultiStreamDetector(model, S, window_duration=2.0, confidence_threshold=0.5, smoothing_window=3,
+                              debounce_seconds=0.5, clock=lambda: now["t"])
+    assert det.pre.get_expected_time_frames() == 201
+    refs = [oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"]) for _ in range(S)]
+    for r in refs:
+        r.windower = ofeat.RealtimeWindowerOracle(window_duration=2.0, hop_duration=0.25)
+    streams = np.stack([synth.make_stream(30 + s, 5.0) for s in range(S)])
+    got, want = [], []
+    for i in range(0, streams.shape[1], 1600):
+        now["t"] = (i + 1600) / 16000.0
+        got.append(sorted(d[0] for d in det.push(streams[:, i:i + 1600])))
+        want.append(sorted(s for s in range(S) if refs[s].process_audio_chunk(streams[s, i:i + 1600]) is not None))
+    for s in range(S):
+        assert len(det.window_probs[s]) == len(refs[s].window_probs) == 13
+        assert np.abs(np.array(det.window_probs[s]) - np.array(refs[s].window_probs)).max() < 1e-3
+    assert got == want
