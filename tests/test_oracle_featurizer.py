@@ -33,23 +33,25 @@ def test_filterbank_against_transformers_and_float64():
     assert np.abs(fb - tfb).max() < 1e-5
 
 
-def _third_party_features(wav: np.ndarray) -> np.ndarray:
-    """The shipped 90x101 feature image computed WITHOUT any code of this repo: transformers.audio_utils
-    (window_function, mel_filter_bank, spectrogram with its own framing / FFT / mel projection / power_to_db / db_range)
-    + scipy's DCT + numpy for the z-score and the delta.  transformers frames `frame_length = 400` samples after a
-    200-sample reflect pad and zero-pads each frame at the END to 512, torch.stft frames 512 samples after a 256-sample
-    reflect pad with the window centred: the windowed samples are the same, the spectra differ by a time shift, the
-    POWER is the same."""
+def _third_party_features(wav: np.ndarray, sample_rate: int = 16000, n_mels: int = 64, hop_length: int = 160,
+                          win_length: int = 400, f_min: float = 100.0, f_max: float = 4000.0, n_mfcc: int = 13) -> np.ndarray:
+    """The (n_mels + 2 n_mfcc) x T feature image (shipped: 90x101) computed WITHOUT any code of this repo:
+    transformers.audio_utils (window_function, mel_filter_bank, spectrogram with its own framing / FFT / mel projection /
+    power_to_db / db_range) + scipy's DCT + numpy for the z-score and the delta.  transformers frames `frame_length =
+    win_length` samples after a win_length / 2 reflect pad and zero-pads each frame at the END to 512, torch.stft frames 512
+    samples after a 256-sample reflect pad with the window centred: for an EVEN win_length the windowed samples are the
+    same, the spectra differ by a time shift, the POWER is the same."""
     tr = pytest.importorskip("transformers.audio_utils")
     from scipy.fft import dct
-    win = tr.window_function(400, "hann", periodic=True)
-    fb = tr.mel_filter_bank(257, 64, 100.0, 4000.0, 16000, norm=None, mel_scale="htk")
-    db = tr.spectrogram(wav.astype(np.float64), window=win, frame_length=400, hop_length=160, fft_length=512, power=2.0,
-                        center=True, pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB", reference=1.0,
-                        min_value=1e-10, db_range=80.0, dtype=np.float64)          # (64, 101) dB, per-clip 80 dB floor
-    assert db.shape == (64, 101)
+    assert win_length % 2 == 0
+    win = tr.window_function(win_length, "hann", periodic=True)
+    fb = tr.mel_filter_bank(257, n_mels, f_min, f_max, sample_rate, norm=None, mel_scale="htk")
+    db = tr.spectrogram(wav.astype(np.float64), window=win, frame_length=win_length, hop_length=hop_length, fft_length=512,
+                        power=2.0, center=True, pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB",
+                        reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64)   # (n_mels, T) dB, per-clip 80 dB floor
+    assert db.shape == (n_mels, 1 + len(wav) // hop_length)
     mel = np.clip((db + 80.0) / 80.0, 0.0, 1.0)                                    # preprocessing.py:409-410
-    mf = dct(db, type=2, norm="ortho", axis=0)[:13]                                # T.MFCC(log_mels=False): DCT of the dB
+    mf = dct(db, type=2, norm="ortho", axis=0)[:n_mfcc]                            # T.MFCC(log_mels=False): DCT of the dB
     mf = (mf - mf.mean()) / (mf.std(ddof=1) + 1e-8)                                # preprocessing.py:428 (torch.std: unbiased)
     pad = np.pad(mf, ((0, 0), (1, 1)), mode="edge")
     delta = (pad[:, 2:] - pad[:, :-2]) / 2.0                                       # preprocessing.py:342-356
@@ -119,6 +121,29 @@ def geometry_clip(seed: int, n: int) -> np.ndarray:
     """A synthetic clip of n samples: the 1 s recipes tiled / cut (quiet floor + bursts exercise the top_db floor)."""
     parts = [synth.make_clip(seed + 7 * k) for k in range((n + 15999) // 16000)]
     return np.concatenate(parts)[:n].astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["mels40_fmax8k", "mels80_mfcc20", "mels128_mfcc40_fmin20", "half_second", "two_seconds",
+                                  "hop128_win512"])
+def test_generic_geometry_restatement_against_third_party_code(name):
+    """The restatement at the constructor's OTHER geometries against transformers + scipy (code the builder did not write):
+    the parameters n_mels / n_mfcc / f_min / f_max / hop / win / segment length are honoured the way independent code
+    honours them."""
+    g = dict(sample_rate=16000, n_mels=64, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13,
+             segment_duration=1.0)
+    g.update(GEOMETRIES[name])
+    n = int(g["sample_rate"] * g.pop("segment_duration"))
+    worst_mel = worst_rest = 0.0
+    for seed in (0, 2, 3, 4, 5):
+        x = geometry_clip(seed, n)
+        ref = F.extract_features(torch.from_numpy(x)[None], **F.geometry_kwargs(**g))[0].numpy()
+        got = _third_party_features(x, **g)
+        nm = g["n_mels"]
+        assert got.shape == ref.shape
+        worst_mel = max(worst_mel, np.abs(got[:nm] - ref[:nm]).max())
+        worst_rest = max(worst_rest, (np.abs(got[nm:] - ref[nm:]) / np.maximum(np.abs(ref[nm:]), 1.0)).max())
+    print(f"{name}: oracle vs transformers+scipy: mel {worst_mel:.2e}, mfcc/delta {worst_rest:.2e}")
+    assert worst_mel < 3e-5 and worst_rest < 5e-5
 
 
 @pytest.mark.parametrize("name", sorted(GEOMETRIES))
