@@ -10,7 +10,8 @@ Differences a caller can observe:
 * ``device`` names where results are RETURNED ("cpu" as the reference's inference engine
   passes, or "cuda"); compute is always on the MI355X -- there is no CPU fallback.
 * ``extract_features`` additionally accepts ``(B, N)`` / ``(B, 1, N)`` batches and returns
-  ``(B, F, T)`` with the reference's per-clip reduction semantics.
+  ``(B, F, T)`` with the reference's per-clip reduction semantics; like the reference it takes a waveform of ANY
+  length N (T = 1 + N // hop_length): ``segment_samples`` runs on the tuned kernel, other lengths on the generic chain.
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
   spectral contrast + centroid) for every geometry at ``n_fft=512``: any ``sample_rate`` / ``hop_length`` /
   ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The shipped geometry
@@ -110,37 +111,59 @@ class AudioPreprocessor:
         self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
         self._dct = _tables.dct_matrix(n_mfcc, n_mels)
         self._handle: Optional[C.c_void_p] = None
-        self._ws: Optional[torch.Tensor] = None     # spectrogram scratch of the spectral-contrast rows
+        self._length_handles = {}                   # other waveform lengths -> featuriser handles (extract_features of any N)
+        self._ws: Optional[torch.Tensor] = None     # scratch of the spectral-contrast rows / the generic kernel chain
         self._resamplers = {}
 
     # ------------------------------------------------------------------ native handle
-    def _native(self) -> C.c_void_p:
+    MAX_LENGTH_HANDLES = 16
+
+    def _native(self, n_samples: Optional[int] = None) -> C.c_void_p:
+        """The featuriser handle for windows of ``n_samples`` (default: ``segment_samples``).  The reference's
+        ``extract_features`` takes a waveform of ANY length (T = 1 + N // hop_length, ``src/preprocessing.py:432-489``); a
+        length other than the constructor's segment gets a handle of its own (generic kernel chain), cached per length."""
+        if n_samples is not None and n_samples != self.segment_samples:
+            h = self._length_handles.get(n_samples)
+            if h is None:
+                if n_samples <= self.n_fft // 2:
+                    raise ValueError(f"a waveform of {n_samples} samples is shorter than the reflect padding of "
+                                     f"torch.stft(center=True) (needs more than n_fft // 2 = {self.n_fft // 2})")
+                if len(self._length_handles) >= self.MAX_LENGTH_HANDLES:          # drop the oldest length
+                    old = next(iter(self._length_handles))
+                    _lib.load().cough_featurizer_destroy(self._length_handles.pop(old))
+                h = self._length_handles[n_samples] = self._create_handle(n_samples)
+            return h
         if self._handle is None:
-            lib = _lib.load()
-            _cuda_device()
-            cfg = _lib.FeatConfig(self.sample_rate, self.n_fft, self.hop_length, self.win_length, self.n_mels,
-                                  self.n_mfcc, self.segment_samples, int(bool(self.use_pre_emphasis)),
-                                  float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)),
-                                  int(bool(self.use_pcen)), int(bool(self.use_mfcc)),
-                                  int(bool(self.use_spectral_contrast)), int(self.n_contrast_bands))
-            if self.use_spectral_contrast:
-                edges = _tables.contrast_band_edges(self.n_contrast_bands, self.n_fft // 2 + 1)
-                for k, e in enumerate(edges):
-                    cfg.contrast_edges[k] = int(e)
-            h = C.c_void_p()
-            _lib.check(lib.cough_featurizer_create(C.byref(h), C.byref(cfg), _lib.fptr(self._window),
-                                                   _lib.fptr(self._mel_fb), _lib.fptr(self._dct)),
-                       "cough_featurizer_create")
-            self._handle = h
+            self._handle = self._create_handle(self.segment_samples)
         return self._handle
 
+    def _create_handle(self, n_samples: int) -> C.c_void_p:
+        lib = _lib.load()
+        _cuda_device()
+        cfg = _lib.FeatConfig(self.sample_rate, self.n_fft, self.hop_length, self.win_length, self.n_mels,
+                              self.n_mfcc, n_samples, int(bool(self.use_pre_emphasis)),
+                              float(self.pre_emphasis_coef), int(bool(self.use_delta_delta)),
+                              int(bool(self.use_pcen)), int(bool(self.use_mfcc)),
+                              int(bool(self.use_spectral_contrast)), int(self.n_contrast_bands))
+        if self.use_spectral_contrast:
+            edges = _tables.contrast_band_edges(self.n_contrast_bands, self.n_fft // 2 + 1)
+            for k, e in enumerate(edges):
+                cfg.contrast_edges[k] = int(e)
+        h = C.c_void_p()
+        _lib.check(lib.cough_featurizer_create(C.byref(h), C.byref(cfg), _lib.fptr(self._window),
+                                               _lib.fptr(self._mel_fb), _lib.fptr(self._dct)),
+                   "cough_featurizer_create")
+        return h
+
     def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
-        if h is not None:
-            try:
-                _lib.load().cough_featurizer_destroy(h)
-            except Exception:
-                pass
+        handles = [getattr(self, "_handle", None)] + list(getattr(self, "_length_handles", {}).values())
+        self._handle, self._length_handles = None, {}
+        for h in handles:
+            if h is not None:
+                try:
+                    _lib.load().cough_featurizer_destroy(h)
+                except Exception:
+                    pass
 
     # ------------------------------------------------------------------ reference helpers (host plumbing)
     def load_audio(self, path: str):
@@ -227,16 +250,18 @@ class AudioPreprocessor:
 
     def featurize_batch(self, waveforms: torch.Tensor, normalize: bool = False,
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """(B, segment_samples) float32 on the GPU -> (B, F, T) float32 on the GPU (stream-ordered,
-        no host sync).  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
-        if waveforms.dim() != 2 or waveforms.shape[1] != self.segment_samples:
-            raise ValueError(f"featurize_batch: expected (B, {self.segment_samples}), got {tuple(waveforms.shape)}")
+        """(B, N) float32 on the GPU -> (B, F, 1 + N // hop_length) float32 on the GPU (stream-ordered, no host sync);
+        N = ``segment_samples`` is the tuned path, any other length runs on the generic kernel chain with a handle
+        cached per length.  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
+        if waveforms.dim() != 2 or waveforms.shape[1] < 1:
+            raise ValueError(f"featurize_batch: expected (B, N), got {tuple(waveforms.shape)}")
+        n_samples = waveforms.shape[1]
         dev = _cuda_device()
         w = waveforms.to(device=dev, dtype=torch.float32)
         if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
             w = w.contiguous()
         b = w.shape[0]
-        f, t = self.get_num_features(), self.get_expected_time_frames()
+        f, t = self.get_num_features(), n_samples // self.hop_length + 1
         if out is None:
             out = torch.empty((b, f, t), dtype=torch.float32, device=dev)
         elif tuple(out.shape) != (b, f, t) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
@@ -244,9 +269,9 @@ class AudioPreprocessor:
         if b == 0:
             return out
         stream = torch.cuda.current_stream(dev).cuda_stream
-        stride = w.stride(0) if b > 1 else self.segment_samples
-        lib, h = _lib.load(), self._native()
-        need = lib.cough_featurizer_workspace_bytes(h, b)      # non-zero only with spectral contrast
+        stride = w.stride(0) if b > 1 else n_samples
+        lib, h = _lib.load(), self._native(n_samples)
+        need = lib.cough_featurizer_workspace_bytes(h, b)      # non-zero with spectral contrast / on the generic chain
         ws = None
         if need:
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
@@ -264,15 +289,16 @@ class AudioPreprocessor:
         ``power=2.0`` with the featuriser's window is the reference's ``self.spectrogram`` (T.Spectrogram,
         preprocessing.py:131-136); ``power=1.0, full_window=True`` is the magnitude spectrogram
         ``T.SpectralCentroid`` (:137-141) forms with its default Hann(n_fft) window."""
-        if waveforms.dim() != 2 or waveforms.shape[1] != self.segment_samples:
-            raise ValueError(f"spectrogram_batch: expected (B, {self.segment_samples}), got {tuple(waveforms.shape)}")
+        if waveforms.dim() != 2 or waveforms.shape[1] < 1:
+            raise ValueError(f"spectrogram_batch: expected (B, N), got {tuple(waveforms.shape)}")
+        n_samples = waveforms.shape[1]
         if power not in (1.0, 2.0):
             raise ValueError("spectrogram_batch: power must be 1.0 or 2.0")
         dev = _cuda_device()
         w = waveforms.to(device=dev, dtype=torch.float32)
         if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
             w = w.contiguous()
-        b, shape = w.shape[0], (w.shape[0], self.n_fft // 2 + 1, self.get_expected_time_frames())
+        b, shape = w.shape[0], (w.shape[0], self.n_fft // 2 + 1, n_samples // self.hop_length + 1)
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=dev)
         elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
@@ -280,8 +306,8 @@ class AudioPreprocessor:
         if b == 0:
             return out
         flags = (_lib.SPEC_MAGNITUDE if power == 1.0 else 0) | (_lib.SPEC_FULL_WINDOW if full_window else 0)
-        _lib.check(_lib.load().cough_spectrogram(self._native(), w.data_ptr(), w.stride(0) if b > 1 else
-                                                 self.segment_samples, out.data_ptr(), b, flags,
+        _lib.check(_lib.load().cough_spectrogram(self._native(n_samples), w.data_ptr(), w.stride(0) if b > 1 else
+                                                 n_samples, out.data_ptr(), b, flags,
                                                  torch.cuda.current_stream(dev).cuda_stream), "cough_spectrogram")
         return out
 
@@ -293,10 +319,7 @@ class AudioPreprocessor:
             waveform = waveform[:, 0]
         if waveform.dim() != 2:
             raise ValueError(f"extract_features: expected (1, N) or (B, N), got {tuple(waveform.shape)}")
-        if waveform.shape[1] != self.segment_samples:
-            raise ValueError(f"extract_features: the MI355X path takes windows of exactly {self.segment_samples} "
-                             f"samples (got {waveform.shape[1]}); use pad_or_trim() / process()")
-        return self.featurize_batch(waveform).to(self._out_device(waveform))
+        return self.featurize_batch(waveform).to(self._out_device(waveform))      # any length, as the reference (:432-489)
 
     def extract_mel_spectrogram(self, waveform: torch.Tensor) -> torch.Tensor:
         return self.extract_features(waveform)[:, :self.n_mels]

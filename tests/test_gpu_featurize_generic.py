@@ -191,3 +191,25 @@ def test_multi_stream_detector_with_two_second_windows_and_hip_graphs():
         assert len(det.window_probs[s]) == len(refs[s].window_probs) == 13
         assert np.abs(np.array(det.window_probs[s]) - np.array(refs[s].window_probs)).max() < 1e-3
     assert got == want
+
+
+def test_extract_features_takes_a_waveform_of_any_length_like_the_reference():
+    """/root/reference/src/preprocessing.py:432-489 never checks the length: (1, N) -> (1, F, 1 + N // hop).  One
+    preprocessor (shipped geometry: its 16000-sample windows stay on the tuned kernel) featurises other lengths through
+    per-length handles on the generic chain; results vs the oracle, and the tuned path is unaffected in between."""
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    one = torch.from_numpy(geometry_clip(3, 16000))[None]
+    base = pre.extract_features(one.cuda())
+    for n in (12345, 40000, 257, 16001):
+        w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in (0, 4)]))
+        f = pre.extract_features(w.cuda())
+        ref = ofeat.extract_features_batch(w)
+        assert f.shape == ref.shape == (2, 90, 1 + n // 160)
+        mel, rel = errors(f, ref, 64)
+        print(f"N = {n}: {tuple(f.shape)} mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+        assert mel < FEAT_TOL and rel < 2 * FEAT_TOL
+        spec = pre.spectrogram_batch(w.cuda())
+        assert spec.shape == (2, 257, 1 + n // 160)
+    assert torch.equal(pre.extract_features(one.cuda()), base) and len(pre._length_handles) == 4
+    with pytest.raises(ValueError, match="reflect padding"):
+        pre.extract_features(torch.zeros(1, 200))
