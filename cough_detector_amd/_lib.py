@@ -46,7 +46,7 @@ SYMBOLS = (
     "cough_cnn_create", "cough_cnn_destroy", "cough_cnn_workspace_bytes", "cough_cnn_forward", "cough_cnn_conv_output",
     "cough_pipeline_workspace_bytes", "cough_pipeline_forward",
     "cough_mask_axes", "cough_prepare_clip", "cough_resample", "cough_ring_write", "cough_window_gather",
-    "cough_synth_clips",
+    "cough_synth_clips", "cough_pre_emphasis", "cough_compute_deltas", "cough_pcen",
 )
 
 
@@ -150,7 +150,10 @@ def load() -> C.CDLL:
         lib.cough_ring_write.argtypes = [vp, i, vp, i, vp, vp, i, vp]
         lib.cough_window_gather.argtypes = [vp, i, vp, vp, i, i, vp, vp]
         lib.cough_synth_clips.argtypes = [vp, ll, i, ll, ll, vp]
-        if lib.cough_amd_abi_version() != 3:
+        lib.cough_pre_emphasis.argtypes = [vp, ll, vp, ll, i, i, C.c_float, vp]
+        lib.cough_compute_deltas.argtypes = [vp, vp, ll, i, vp]
+        lib.cough_pcen.argtypes = [vp, vp, ll, i, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+        if lib.cough_amd_abi_version() != 4:
             raise RuntimeError("libcough_amd.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

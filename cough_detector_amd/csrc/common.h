@@ -54,6 +54,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// A float32 product the compiler cannot contract into an FMA with a neighbouring add / subtract: hipcc's __fmul_rn / __fadd_rn
+// are the plain operators, and under HIP's default -ffp-contract=fast `__fsub_rn(x, __fmul_rn(c, y))` becomes ONE v_fma_f32
+// (exact product), 1 ulp away from torch's separately rounded `x - c * y` in a third of the elements.  Wherever the
+// reference's arithmetic is two IEEE operations (pre-emphasis, the clip generator's parameter arithmetic) use this.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Intra-wave LDS hand-off: LDS executes a wave's accesses in order, so only the compiler
 // has to be kept from reordering across this point.
 __device__ __forceinline__ void wave_lds_fence() {

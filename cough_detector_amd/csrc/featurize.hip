@@ -233,8 +233,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 int i0 = s0 + 32 * n1, i1 = i0 + 1;
                 i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
                 i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
-                const float p0 = i0 > 0 ? __fmul_rn(pre_coef, x[i0 - 1]) : 0.f;
-                const float p1 = i1 > 0 ? __fmul_rn(pre_coef, x[i1 - 1]) : 0.f;
+                const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
+                const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
                 const float x0 = x[i0], x1 = x[i1];
                 peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));   // the peak is of x, not of the emphasised signal
                 a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);

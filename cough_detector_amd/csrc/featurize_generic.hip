@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     };
     auto value = [&](int i) -> float {   // sample i of the (normalised, pre-emphasised) signal, i already inside the clip
         float v = sample(i);
-        if (pre_emph && i > 0) v = __fsub_rn(v, __fmul_rn(coef, sample(i - 1)));   // y[n] = x[n] - coef x[n-1], y[0] = x[0]
+        if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));   // y[n] = x[n] - coef x[n-1], y[0] = x[0]
         return v;
     };
     float2 a[16], z[16];
@@ -335,6 +335,39 @@ __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stand-alone helpers
+// AudioPreprocessor.apply_pre_emphasis / compute_deltas / apply_pcen called on their own (:214-240, :342-356, :305-340)
+__global__ __launch_bounds__(256) void pre_emphasis_kernel(const float* __restrict__ in, long long in_stride, float* __restrict__ out,
+                                                           long long out_stride, int n, float coef) {
+    const float* x = in + blockIdx.y * in_stride;
+    float* y = out + blockIdx.y * out_stride;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = i > 0 ? __fsub_rn(x[i], mul_rn(coef, x[i - 1])) : x[i];   // first sample kept
+}
+__global__ __launch_bounds__(256) void deltas_kernel(const float* __restrict__ in, float* __restrict__ out, long long total, int T) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const int t = int(i % T);
+    const float* row = in + (i - t);
+    const int a = t + 1 < T ? t + 1 : T - 1, b = t - 1 > 0 ? t - 1 : 0;   // replicate padding
+    out[i] = (row[a] - row[b]) / 2.0f;
+}
+__global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ in, float* __restrict__ out, long long total, int T,
+                                                   float alpha, float delta, float r, float eps, float delta_pow_r) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const int t = int(i % T);
+    const float* row = in + (i - t);
+    float sm = 0.f;
+#pragma unroll
+    for (int q = -5; q < 5; ++q) {   // avg_pool2d(kernel (1, 10), padding (0, 5), zeros counted), trimmed to T
+        const int u = t + q;
+        sm += (u >= 0 && u < T) ? row[u] : 0.f;
+    }
+    const float base = row[t] / powf(eps + sm / 10.0f, alpha) + delta;
+    out[i] = (r == 0.5f ? sqrtf(base) : powf(base, r)) - delta_pow_r;
+}
+
 size_t align256g(size_t v) { return (v + 255) & ~size_t(255); }
 
 }  // namespace
@@ -558,3 +591,43 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
 }
 
 }  // namespace cough
+
+extern "C" int cough_pre_emphasis(const float* d_in, long long in_stride, float* d_out, long long out_stride, int n_rows,
+                                  int n, float coef, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_in && d_out, COUGH_EINVAL, "cough_pre_emphasis: NULL argument");
+    COUGH_REQUIRE(n_rows >= 0 && n >= 0 && in_stride >= n && out_stride >= n, COUGH_EINVAL, "cough_pre_emphasis: bad shape");
+    COUGH_REQUIRE(d_in != d_out, COUGH_EINVAL, "cough_pre_emphasis: in-place operation is not supported");
+    if (n_rows == 0 || n == 0) return COUGH_OK;
+    COUGH_REQUIRE(n_rows <= 65535, COUGH_EUNSUPPORTED, "cough_pre_emphasis: at most 65535 rows per call");
+    hipLaunchKernelGGL(pre_emphasis_kernel, dim3((n + 255) / 256, n_rows), dim3(256), 0, static_cast<hipStream_t>(stream), d_in,
+                       in_stride, d_out, out_stride, n, coef);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+extern "C" int cough_compute_deltas(const float* d_in, float* d_out, long long n_rows, int n_frames, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_in && d_out, COUGH_EINVAL, "cough_compute_deltas: NULL argument");
+    COUGH_REQUIRE(n_rows >= 0 && n_frames >= 0 && d_in != d_out, COUGH_EINVAL, "cough_compute_deltas: bad shape / in-place");
+    const long long total = n_rows * n_frames;
+    if (total == 0) return COUGH_OK;
+    hipLaunchKernelGGL(deltas_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_in,
+                       d_out, total, n_frames);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}
+
+extern "C" int cough_pcen(const float* d_mel, float* d_out, long long n_rows, int n_frames, float alpha, float delta, float r,
+                          float eps, void* stream) {
+    using namespace cough;
+    COUGH_REQUIRE(d_mel && d_out, COUGH_EINVAL, "cough_pcen: NULL argument");
+    COUGH_REQUIRE(n_rows >= 0 && n_frames >= 0 && d_mel != d_out, COUGH_EINVAL, "cough_pcen: bad shape / in-place");
+    const long long total = n_rows * n_frames;
+    if (total == 0) return COUGH_OK;
+    const float dpr = float(std::pow(double(delta), double(r)));   // `delta ** r` is a Python float in the reference
+    hipLaunchKernelGGL(pcen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_mel,
+                       d_out, total, n_frames, alpha, delta, r, eps, dpr);
+    COUGH_HIP_CHECK(hipGetLastError());
+    return COUGH_OK;
+}

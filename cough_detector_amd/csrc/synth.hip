@@ -33,12 +33,12 @@ __device__ __forceinline__ float param(uint32_t seed, int p) { return u01(key(se
 // large argument and the host mirror reproduces it bit for bit
 __device__ __forceinline__ float tone(int fq, int i) {
     const uint32_t r = (uint32_t(fq) * uint32_t(i)) % 256000u;
-    return sinf(TWO_PI * __fmul_rn(float(r), 3.90625e-6f));
+    return sinf(TWO_PI * mul_rn(float(r), 3.90625e-6f));
 }
-__device__ __forceinline__ int freq16(float lo16, float span16, float x) { return int(__fadd_rn(lo16, __fmul_rn(span16, x))); }
+__device__ __forceinline__ int freq16(float lo16, float span16, float x) { return int(__fadd_rn(lo16, mul_rn(span16, x))); }
 // parameter arithmetic is pinned to separate IEEE multiplies / adds (no FMA contraction): the host mirror must
 // reproduce every floor() below exactly
-__device__ __forceinline__ float affine(float a, float b, float x) { return __fadd_rn(a, __fmul_rn(b, x)); }
+__device__ __forceinline__ float affine(float a, float b, float x) { return __fadd_rn(a, mul_rn(b, x)); }
 
 __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ out, long long stride, long long first_seed,
                                                           long long seed_stride) {
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
     float* o = out + (long long)blockIdx.x * stride;
     if (kind == 0) {          // cough-like burst: 20 ms linear attack + exp(-5u) decay over a noise floor
         const float dur = affine(0.3f, 0.5f, param(seed, 0));
-        const int n_burst = int(__fmul_rn(dur, 16000.0f));
-        const int start = int(__fmul_rn(__fmul_rn(param(seed, 1), __fsub_rn(1.0f, dur)), 16000.0f));
+        const int n_burst = int(mul_rn(dur, 16000.0f));
+        const int start = int(mul_rn(mul_rn(param(seed, 1), __fsub_rn(1.0f, dur)), 16000.0f));
         const int n_att = 320;
         const int f1 = freq16(1280.0f, 1120.0f, param(seed, 2)), f2 = freq16(3200.0f, 3200.0f, param(seed, 3));   // 80-150, 200-400 Hz
         const float inv_att = 1.0f / float(n_att - 1), inv_dec = 5.0f / float(n_burst - n_att - 1);
@@ -78,16 +78,16 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
         const float sigma = affine(0.02f, 0.08f, param(seed, 0));
         for (int i = tid; i < SN; i += 256) o[i] = sigma * normal(seed, 1, i);
     } else if (kind == 3) {   // mains-like hum
-        const int sel = int(__fmul_rn(param(seed, 0), 4.0f));
+        const int sel = int(mul_rn(param(seed, 0), 4.0f));
         const int f = sel == 0 ? 800 : sel == 1 ? 960 : sel == 2 ? 1600 : 1920;   // 50 / 60 / 100 / 120 Hz
         for (int i = tid; i < SN; i += 256) o[i] = 0.1f * tone(f, i) + 0.02f * normal(seed, 1, i);
     } else if (kind == 4) {   // clicks on a floor: 1-4 plateaus of 50 samples, later ones overwrite earlier ones
-        const int cnt = 1 + int(__fmul_rn(param(seed, 0), 4.0f));
+        const int cnt = 1 + int(mul_rn(param(seed, 0), 4.0f));
         int pos[4];
         float val[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            pos[c] = int(__fmul_rn(param(seed, 1 + 2 * c), float(SN - 100)));
+            pos[c] = int(mul_rn(param(seed, 1 + 2 * c), float(SN - 100)));
             val[c] = affine(-0.3f, 0.6f, param(seed, 2 + 2 * c));
         }
         for (int i = tid; i < SN; i += 256) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void synth_clips_kernel(float* __restrict__ ou
             o[i] = v;
         }
     } else {                  // speech-like stack of 2-4 sines
-        const int cnt = 2 + int(__fmul_rn(param(seed, 0), 3.0f));
+        const int cnt = 2 + int(mul_rn(param(seed, 0), 3.0f));
         int f[4];
         float a[4];
 #pragma unroll

@@ -219,6 +219,45 @@ class AudioPreprocessor:
             return waveform / max_val if max_val > 0 else waveform
         return self._prepare(waveform, waveform.shape[1], True).to(waveform.device)
 
+    def _rows_op(self, x: torch.Tensor, launch) -> torch.Tensor:
+        """Run a row-wise kernel over the last axis of ``x`` on the GPU; the result comes back where ``x`` lives."""
+        dev = _cuda_device()
+        xin = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        out = torch.empty_like(xin)
+        if xin.numel():
+            launch(xin, out, torch.cuda.current_stream(dev).cuda_stream)
+        return out.to(x.device)
+
+    def apply_pre_emphasis(self, waveform: torch.Tensor) -> torch.Tensor:
+        """y[n] = x[n] - coef * x[n-1], first sample kept (src/preprocessing.py:214-240); identity unless the preprocessor
+        was built with ``use_pre_emphasis=True``.  ``extract_features`` applies it inside the featurise kernel."""
+        if not self.use_pre_emphasis:
+            return waveform
+        if waveform.dim() != 2:
+            raise ValueError(f"apply_pre_emphasis: expected (channels, samples), got {tuple(waveform.shape)}")
+        return self._rows_op(waveform, lambda a, o, st: _lib.check(_lib.load().cough_pre_emphasis(
+            a.data_ptr(), a.shape[1], o.data_ptr(), a.shape[1], a.shape[0], a.shape[1], float(self.pre_emphasis_coef), st),
+            "cough_pre_emphasis"))
+
+    def compute_deltas(self, features: torch.Tensor) -> torch.Tensor:
+        """(channels, freq, time) -> same shape: replicate-padded central difference / 2 (src/preprocessing.py:342-356)."""
+        if features.dim() < 1 or features.shape[-1] < 1:
+            raise ValueError(f"compute_deltas: expected (..., time), got {tuple(features.shape)}")
+        t = features.shape[-1]
+        return self._rows_op(features, lambda a, o, st: _lib.check(_lib.load().cough_compute_deltas(
+            a.data_ptr(), o.data_ptr(), a.numel() // t, t, st), "cough_compute_deltas"))
+
+    def apply_pcen(self, mel_spec: torch.Tensor, alpha: float = 0.98, delta: float = 2.0, r: float = 0.5,
+                   eps: float = 1e-6) -> torch.Tensor:
+        """Per-channel energy normalisation of a mel POWER spectrogram (channels, n_mels, time)
+        (src/preprocessing.py:305-340): 10-frame moving average, (mel / (eps + smooth)^alpha + delta)^r - delta^r."""
+        if mel_spec.dim() != 3:
+            raise ValueError(f"apply_pcen: expected (channels, n_mels, time), got {tuple(mel_spec.shape)}")
+        t = mel_spec.shape[-1]
+        return self._rows_op(mel_spec, lambda a, o, st: _lib.check(_lib.load().cough_pcen(
+            a.data_ptr(), o.data_ptr(), a.numel() // max(t, 1), t, float(alpha), float(delta), float(r), float(eps), st),
+            "cough_pcen"))
+
     def pad_or_trim(self, waveform: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:
         if length is None:
             length = self.segment_samples

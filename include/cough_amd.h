@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COUGH_AMD_ABI_VERSION 3
+#define COUGH_AMD_ABI_VERSION 4
 
 #define COUGH_OK 0
 #define COUGH_EINVAL 1        /* bad argument (NULL, negative size, misaligned pointer) */
@@ -116,6 +116,20 @@ int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long 
 #define COUGH_SPEC_FULL_WINDOW 2
 int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                       float* d_spec, int n_clips, int flags, void* stream);
+
+/* The three helper methods of AudioPreprocessor a caller may use on their own (extract_features fuses them):
+ *   cough_pre_emphasis   apply_pre_emphasis (/root/reference/src/preprocessing.py:214-240): y[0] = x[0],
+ *                        y[n] = x[n] - coef * x[n-1] per row (the product and the difference rounded separately, as torch);
+ *   cough_compute_deltas compute_deltas (:342-356): replicate-pad the last axis by one, (x[t+1] - x[t-1]) / 2, over
+ *                        n_rows contiguous rows of n_frames values;
+ *   cough_pcen           apply_pcen (:305-340): smooth = 10-frame moving average (avg_pool2d kernel (1, 10), padding (0, 5),
+ *                        trimmed to n_frames), (mel / (eps + smooth)^alpha + delta)^r - delta^r.
+ * Out-of-place only (d_out != d_in). */
+int cough_pre_emphasis(const float* d_in, long long in_stride, float* d_out, long long out_stride, int n_rows, int n,
+                       float coef, void* stream);
+int cough_compute_deltas(const float* d_in, float* d_out, long long n_rows, int n_frames, void* stream);
+int cough_pcen(const float* d_mel, float* d_out, long long n_rows, int n_frames, float alpha, float delta, float r,
+               float eps, void* stream);
 
 /* ------------------------------------------------------------------ classifier (K2-K5)
  * Replaces CoughDetectorResidual.forward / predict and ResidualBlock.forward

@@ -344,3 +344,28 @@ def test_prepare_clip_is_bit_exact(pre, channels, n):
     mono = pre.to_mono(w)                                      # the reference's helper methods run the same kernel
     assert not mono.is_cuda and torch.equal(mono, ofeat.to_mono(w))
     assert torch.equal(pre.normalize(mono), ofeat.normalize(ofeat.to_mono(w)))
+
+
+def test_helper_methods_called_on_their_own():
+    """apply_pre_emphasis / compute_deltas / apply_pcen are public methods of the reference class
+    (/root/reference/src/preprocessing.py:214-240, :342-356, :305-340); extract_features fuses them, a caller may also use
+    them directly.  Pre-emphasis and the deltas are single IEEE operations per element: bit-exact vs the restatement."""
+    rng = np.random.default_rng(7)
+    on = cda.AudioPreprocessor(device="cuda", **{**SHIPPED, "use_pre_emphasis": True})
+    off = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    w = torch.from_numpy(rng.standard_normal((2, 16000)).astype(np.float32))
+    assert off.apply_pre_emphasis(w) is w                                        # flag off: returned as is (:231-232)
+    got = on.apply_pre_emphasis(w)
+    assert not got.is_cuda and torch.equal(got, ofeat.pre_emphasis(w, 0.97))
+    assert torch.equal(on.apply_pre_emphasis(w.cuda()).cpu(), got)
+    x = torch.from_numpy(rng.standard_normal((3, 13, 101)).astype(np.float32))
+    assert torch.equal(off.compute_deltas(x), ofeat.compute_deltas(x))
+    assert torch.equal(off.compute_deltas(x[:, :, :1]), torch.zeros(3, 13, 1))   # one frame: (x - x) / 2
+    mel = torch.from_numpy((rng.standard_normal((1, 64, 101)) ** 2 * 10).astype(np.float32))
+    for kw in (dict(), dict(alpha=0.9, delta=1.5, r=0.4, eps=1e-5)):
+        ref = ofeat.apply_pcen(mel, **kw)
+        err = ((off.apply_pcen(mel, **kw) - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+        print(f"apply_pcen{kw}: rel err {err:.2e}")
+        assert err < 1e-5
+    with pytest.raises(ValueError, match="apply_pcen"):
+        off.apply_pcen(mel[0])

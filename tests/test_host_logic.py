@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cough_amd_abi_version() == 3
+    assert lib.cough_amd_abi_version() == 4
     assert lib.cough_amd_arch() == b"gfx950"
 
 
