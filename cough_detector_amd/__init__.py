@@ -4,9 +4,10 @@ hand-written HIP kernels (``csrc/``) reached through the C-ABI in ``include/coug
 from .preprocessing import AudioPreprocessor, RealtimePreprocessor, create_preprocessor
 from .model import (CoughDetector, CoughDetectorResidual, CoughDetectorSmall, ConvBlock, ResidualBlock, create_model,
                     count_parameters)
-from .inference import CoughDetectorInference
+from .inference import CoughDetectorInference, RealtimeQueueDetector
 from .pipeline import CoughPipeline
 
 __all__ = ["AudioPreprocessor", "RealtimePreprocessor", "create_preprocessor", "CoughDetectorResidual",
            "CoughDetector", "CoughDetectorSmall", "ConvBlock",
-           "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference", "CoughPipeline"]
+           "ResidualBlock", "create_model", "count_parameters", "CoughDetectorInference", "RealtimeQueueDetector",
+           "CoughPipeline"]

@@ -7,11 +7,14 @@ config contract :119-163, ``predict`` :165-189, ``process_audio_chunk`` :191-241
 completes goes through ONE featurise launch and ONE classifier forward.  The smoothing / debounce
 state machine stays on the host and takes an injectable clock (the reference reads
 ``datetime.now()``, :226,233), so runs are reproducible.  Microphone back-ends (:250-451) are
-hardware I/O and not part of this path; ``main`` reads a synthetic or ``.npy`` stream instead.
+hardware I/O and not part of this path; ``RealtimeQueueDetector`` keeps the queue + consumer-thread structure that drives
+the path (``feed`` = the audio callback) and ``main`` reads a synthetic or ``.npy`` stream instead.
 """
 from __future__ import annotations
 
 import argparse
+import queue
+import threading
 import time
 from collections import deque
 from datetime import datetime
@@ -138,6 +141,74 @@ class CoughDetectorInference:
         self.preprocessor.reset()
         self.prediction_history.clear()
         self.last_detection_time = 0
+
+
+class RealtimeQueueDetector:
+    """The queue-and-consumer-thread half of the reference's ``RealtimeMicrophoneDetector``
+    (``/root/reference/src/inference.py:250-430``) without its audio back-ends: whatever captures audio calls ``feed`` --
+    what the reference's sounddevice / pyaudio callbacks do with ``audio_queue.put(indata.copy())`` (:296-300, :382-386)
+    -- and ONE consumer thread drains the queue into ``inference.process_audio_chunk`` (:302-324), the only place the GPU
+    path is entered.  ``start`` / ``stop`` / ``on_detection`` keep the reference's names and behaviour; detections are also
+    collected in ``detections``.  ``clock_from_samples=True`` drives the engine's clock from the number of samples
+    consumed (reproducible), otherwise the engine's own clock (wall time) is used as in the reference."""
+
+    def __init__(self, inference_engine: CoughDetectorInference, sample_rate: int = 16000, chunk_duration: float = 0.1,
+                 clock_from_samples: bool = False, verbose: bool = False):
+        self.inference = inference_engine
+        self.sample_rate = sample_rate
+        self.chunk_size = int(sample_rate * chunk_duration)
+        self.running = False
+        self.audio_queue: "queue.Queue" = queue.Queue()
+        self.on_detection: Optional[Callable[[datetime, float], None]] = None
+        self.detections = []            # (stream time or wall time, confidence)
+        self.errors = []                # the reference prints and goes on (:323-324); kept for the caller as well
+        self.verbose = verbose
+        self._consumed = 0
+        self._clock_from_samples = clock_from_samples
+
+    def feed(self, chunk) -> None:
+        """The audio callback: enqueue a copy, nothing else."""
+        self.audio_queue.put(np.array(chunk, dtype=np.float32, copy=True))
+
+    def _process_audio(self):
+        while self.running or not self.audio_queue.empty():
+            try:
+                audio_chunk = self.audio_queue.get(timeout=0.05)
+            except queue.Empty:
+                continue
+            try:
+                audio_chunk = audio_chunk.flatten()
+                self._consumed += len(audio_chunk)
+                if self._clock_from_samples:
+                    t = self._consumed / float(self.sample_rate)
+                    self.inference._clock = lambda t=t: t
+                result = self.inference.process_audio_chunk(audio_chunk)
+                if result is not None:
+                    timestamp, confidence = result
+                    self.detections.append((timestamp.timestamp(), confidence))
+                    if self.verbose:
+                        print(f"COUGH DETECTED at {timestamp.strftime('%Y-%m-%d %H:%M:%S.%f')[:-3]}  confidence {confidence:.2%}")
+                    if self.on_detection:
+                        self.on_detection(timestamp, confidence)
+            except Exception as e:      # noqa: BLE001 -- the consumer must survive a bad chunk, as the reference's does
+                self.errors.append(e)
+                if self.verbose:
+                    print(f"Error processing audio: {e}")
+
+    def start(self):
+        if self.running:
+            return
+        self.running = True
+        self.inference.reset()
+        self._consumed = 0
+        self.process_thread = threading.Thread(target=self._process_audio, name="cough-consumer")
+        self.process_thread.start()
+
+    def stop(self, timeout: float = 60.0):
+        """Stop after the queue has been drained (the reference drops what is still queued; a file / test driver wants it all)."""
+        self.running = False
+        if hasattr(self, "process_thread"):
+            self.process_thread.join(timeout=timeout)
 
 
 def main(argv=None):

@@ -110,3 +110,36 @@ def test_two_threads_share_immutable_handles_on_separate_streams():
         t.join(timeout=300)
     assert not errors, errors
     assert results == [True, True]
+
+
+def test_realtime_queue_detector_is_the_reference_consumer_loop(tmp_path):
+    """cough_detector_amd.RealtimeQueueDetector = RealtimeMicrophoneDetector (/root/reference/src/inference.py:250-430) minus
+    the audio back-ends: `feed` is the audio callback, `start` / `stop` / `on_detection` as in the reference.  Same stream,
+    same oracle as above, driven through the product class."""
+    sd = realistic_state_dict(5)
+    path = str(tmp_path / "m.pt")
+    torch.save({"model_state_dict": sd, "config": CONFIG}, path)
+    eng = cda.CoughDetectorInference(path, confidence_threshold=0.5, smoothing_window=3, debounce_seconds=0.5, verbose=False)
+    det = cda.RealtimeQueueDetector(eng, sample_rate=16000, chunk_duration=0.1, clock_from_samples=True)
+    assert det.chunk_size == 1600
+    seen = []
+    det.on_detection = lambda ts, conf: seen.append(conf)
+    det.start()
+    assert det.process_thread.is_alive() and det.process_thread is not threading.main_thread()
+    stream = synth.make_stream(9, 6.0)
+    for i in range(0, len(stream) - 1600 + 1, 1600):
+        det.feed(stream[i:i + 1600].reshape(-1, 1))            # (frames, channels), as sounddevice hands it over
+    det.stop()
+    assert not det.process_thread.is_alive() and not det.errors, det.errors
+    now = {"t": 0.0}
+    ref = oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"])
+    ref_hits = []
+    for i in range(0, len(stream) - 1600 + 1, 1600):
+        now["t"] = (i + 1600) / 16000.0
+        h = ref.process_audio_chunk(stream[i:i + 1600])
+        if h is not None:
+            ref_hits.append(h)
+    assert len(eng.window_probs) == len(ref.window_probs) == 21
+    assert np.abs(np.array(eng.window_probs) - np.array(ref.window_probs)).max() < 1e-3
+    assert [t for t, _ in det.detections] == pytest.approx([t for t, _ in ref_hits])
+    assert len(seen) == len(ref_hits) >= 2 and np.abs(np.array(seen) - np.array([c for _, c in ref_hits])).max() < 1e-3
