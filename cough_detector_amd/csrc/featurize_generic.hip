@@ -174,6 +174,84 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ STFT, any power-of-two n_fft
+// n_fft in {64 .. 2048} other than 512: one WAVE per frame, the n_fft / 2-point complex FFT of the packed real frame as a
+// radix-2 Stockham autosort (ping-pong between two LDS buffers, twiddles from a table computed in double), then the
+// real-input split with W_n_fft^k.  4 frames per workgroup.  Slower than the register radix-16 x radix-16 of the 512-point
+// kernels (the shipped n_fft), and fully general in n_fft.
+template <bool MAG, bool MEL>
+__global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
+                                                            int nfft, const float* __restrict__ win /* [nfft] */,
+                                                            const float2* __restrict__ twn /* [nfft/2 + 1]: W_nfft^k */,
+                                                            const float* __restrict__ peaks, int pre_emph, float coef,
+                                                            float* __restrict__ out, GenMel mel) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    const int NC = nfft / 2, nfreq = NC + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* buf0 = reinterpret_cast<float2*>(smem_p) + size_t(wave) * 2 * NC;
+    float2* buf1 = buf0 + NC;
+    float* spec = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem_p) + size_t(4) * 2 * NC) + size_t(wave) * (nfreq + 1);
+    const long long clip = blockIdx.y;
+    const int t_raw = blockIdx.x * 4 + wave, t = t_raw < T ? t_raw : T - 1;
+    const float* x = wav + clip * stride;
+    const float m = peaks ? peaks[clip] : 0.f;
+    const bool norm = m > 0.f;
+    auto sample = [&](int i) -> float {
+        const float v = x[i];
+        return norm ? v / m : v;
+    };
+    auto value = [&](int i) -> float {
+        i = i < 0 ? -i : (i >= N ? 2 * (N - 1) - i : i);          // reflect padding (N > n_fft / 2: one reflection suffices)
+        float v = sample(i);
+        if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));
+        return v;
+    };
+    const int s0 = hop * t - NC;
+    for (int n = lane; n < NC; n += 64)
+        buf0[n] = make_float2(value(s0 + 2 * n) * win[2 * n], value(s0 + 2 * n + 1) * win[2 * n + 1]);
+    wave_lds_fence();
+    // Stockham autosort, decimation in frequency: stage (l, m), l * m = NC / 2; butterfly b -> (j = b / m, k = b % m)
+    float2* src = buf0;
+    float2* dst = buf1;
+    for (int l = NC >> 1, mm = 1; l >= 1; l >>= 1, mm <<= 1) {
+        for (int b = lane; b < (NC >> 1); b += 64) {
+            const int j = b / mm, k = b - j * mm;
+            const float2 c0 = src[k + j * mm], c1 = src[k + j * mm + l * mm];
+            const float2 w = twn[2 * j * mm];                      // W_{2l}^j = W_NC^{j m} = W_nfft^{2 j m}
+            const float2 d = make_float2(c0.x - c1.x, c0.y - c1.y);
+            dst[k + 2 * j * mm] = make_float2(c0.x + c1.x, c0.y + c1.y);
+            dst[k + 2 * j * mm + mm] = cmul(d, w);
+        }
+        wave_lds_fence();
+        float2* tmp = src; src = dst; dst = tmp;
+    }
+    // real-input split: X[k] = E + W_nfft^k O, E = (Zk + conj Zp) / 2, O = -i (Zk - conj Zp) / 2, Zp = Z[(NC - k) mod NC]
+    for (int k = lane; k <= NC; k += 64) {
+        const float2 zk = src[k == NC ? 0 : k], zq = src[k == 0 || k == NC ? 0 : NC - k];
+        const float ex = 0.5f * (zk.x + zq.x), ey = 0.5f * (zk.y - zq.y);
+        const float ox = 0.5f * (zk.y + zq.y), oy = 0.5f * (zq.x - zk.x);
+        const float2 w = twn[k];
+        const float xr = ex + w.x * ox - w.y * oy, xi = ey + w.x * oy + w.y * ox;
+        const float pw = xr * xr + xi * xi;
+        spec[k] = MAG ? sqrtf(pw) : pw;
+    }
+    wave_lds_fence();
+    if (t_raw >= T) return;
+    if constexpr (MEL) {
+        float* o = out + clip * (long long)mel.n_mels * T;
+        for (int mb = lane; mb < mel.n_mels; mb += 64) {
+            const int l = mel.lo[mb], hb = mel.hi[mb];
+            const float* wm = mel.w + mel.off[mb];
+            float acc = 0.f;
+            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], spec[k], acc);
+            o[(long long)mb * T + t] = acc;
+        }
+    } else {
+        float* o = out + clip * (long long)nfreq * T;
+        for (int k = lane; k <= NC; k += 64) o[(long long)k * T + t] = spec[k];
+    }
+}
+
 // AmplitudeToDB('power'): 10 log10(max(x, amin = 1e-10)) (ref = 1: no offset)
 __device__ __forceinline__ float g_db(float p) { return 10.0f * log10f(fmaxf(p, 1e-10f)); }
 // PCEN value of apply_pcen (:305-340): smooth = 10-frame moving average (avg_pool2d kernel 10, padding 5, zeros counted,
@@ -288,20 +366,20 @@ __global__ __launch_bounds__(256) void gen_delta_kernel(float* __restrict__ feat
 // Per band its rows go to LDS, then each frame ranks its bins (rank = number of smaller values, ties by index -- the
 // position torch.sort would give) and sums the values of rank >= top_idx and < bot_idx: the reference's sorted-slice means
 // without sorting; an empty top slice divides 0 by 0 as the mean of an empty tensor does (:272-293).
-__global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restrict__ P, const float* __restrict__ M, int T,
+__global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restrict__ P, const float* __restrict__ M, int T, int nfreq,
                                                           ContrastCfg cfg, const float* __restrict__ freqs, float nyquist,
                                                           float* __restrict__ feat, int nfeat, int row0) {
     __shared__ float band[G_CT_BINS * G_TT];
     const int lane = threadIdx.x;
     const long long clip = blockIdx.y;
     const int t = blockIdx.x * G_TT + lane;
-    const float* Pc = P + clip * (long long)G_NFREQ * T;
-    const float* Mc = M + clip * (long long)G_NFREQ * T;
+    const float* Pc = P + clip * (long long)nfreq * T;
+    const float* Mc = M + clip * (long long)nfreq * T;
     float* o = feat + (clip * (long long)nfeat + row0) * T;
     for (int i = 0; i < cfg.n_bands; ++i) {
         int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
         if (high <= low) high = low + 1;
-        if (high > G_NFREQ) high = G_NFREQ;
+        if (high > nfreq) high = nfreq;
         const int nb = high - low;
         __syncthreads();
         for (int e = 0; e < nb; ++e) band[e * G_TT + lane] = t < T ? Pc[(long long)(low + e) * T + t] : 0.f;
@@ -326,7 +404,7 @@ __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restric
     }
     if (t < T) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
         float num = 0.f, den = 0.f;
-        for (int k = 0; k < G_NFREQ; ++k) {
+        for (int k = 0; k < nfreq; ++k) {
             const float m = Mc[(long long)k * T + t];
             num += freqs[k] * m;
             den += m;
@@ -369,30 +447,50 @@ __global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ in,
 }
 
 size_t align256g(size_t v) { return (v + 255) & ~size_t(255); }
+size_t pow2_lds_bytes(int nfft) { return size_t(4) * 2 * (nfft / 2) * 8 + size_t(4) * (nfft / 2 + 2) * 4; }
 
 }  // namespace
 
 struct GenFeat {
     int N, hop, T, n_mels, n_mfcc, sample_rate;
+    int nfft, nfreq;       // n_fft (a power of two, 64 .. 2048) and n_fft / 2 + 1
     char* d_blob;
-    const float* win;      // [512] caller's window centred in the frame
-    const float* win_full; // [512] periodic Hann(512)
-    const float2* tw256;   // [16][16]
+    const float* win;      // [n_fft] caller's window centred in the frame
+    const float* win_full; // [n_fft] periodic Hann(n_fft)
+    const float2* tw256;   // [16][16]            (the 512-point kernels)
     const float2* tw512;   // [128]
+    const float2* twn;     // [n_fft / 2 + 1] W_n_fft^k (gen_stft_pow2_kernel)
     const int *mel_lo, *mel_hi, *mel_off;
     const float* mel_w;    // CSR taps
     const float* dct_t;    // [n_mfcc][n_mels]
     const float* freqs;    // [257] torch.linspace(0, sample_rate // 2, 257)
 };
 
+namespace {
+// one STFT launch of the chain: the register radix-16 x radix-16 kernel at n_fft = 512, the Stockham kernel otherwise
+template <bool MAG, bool MEL>
+void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int nc, const float* win, const float* peaks,
+                     int pre_emph, float coef, float* out, const GenMel& mel, hipStream_t stream) {
+    if (g->nfft == G_NFFT) {
+        hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((g->T + G_FPB - 1) / G_FPB, nc), dim3(256), 0, stream, w, wav_stride,
+                           g->N, g->hop, g->T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel);
+    } else {
+        hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
+                           wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
+    }
+}
+}  // namespace
+
 int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* window, const float* mel_fb, const float* dct) {
-    COUGH_REQUIRE(cfg->n_fft == G_NFFT, COUGH_EUNSUPPORTED, "n_fft = %d: the HIP path implements n_fft = 512", cfg->n_fft);
-    COUGH_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= G_NFFT, COUGH_EUNSUPPORTED,
+    const int nfft = cfg->n_fft, nfreq = nfft / 2 + 1;
+    COUGH_REQUIRE(nfft >= 64 && nfft <= 2048 && (nfft & (nfft - 1)) == 0, COUGH_EUNSUPPORTED,
+                  "n_fft = %d: the HIP path implements the powers of two 64 .. 2048 (512 on the register FFT kernels)", nfft);
+    COUGH_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= nfft, COUGH_EUNSUPPORTED,
                   "win_length = %d: need 1 <= win_length <= n_fft", cfg->win_length);
     COUGH_REQUIRE(cfg->hop_length >= 1, COUGH_EINVAL, "hop_length = %d", cfg->hop_length);
-    COUGH_REQUIRE(cfg->segment_samples > G_PADL, COUGH_EUNSUPPORTED,
-                  "segment of %d samples: reflect padding (torch.stft center=True) needs more than n_fft / 2 = 256",
-                  cfg->segment_samples);
+    COUGH_REQUIRE(cfg->segment_samples > nfft / 2, COUGH_EUNSUPPORTED,
+                  "segment of %d samples: reflect padding (torch.stft center=True) needs more than n_fft / 2 = %d",
+                  cfg->segment_samples, nfft / 2);
     COUGH_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= G_MAX_MELS, COUGH_EUNSUPPORTED,
                   "n_mels = %d: the HIP path takes 1..%d", cfg->n_mels, G_MAX_MELS);
     COUGH_REQUIRE(!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= cfg->n_mels), COUGH_EINVAL,
@@ -400,12 +498,16 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     COUGH_REQUIRE(cfg->sample_rate >= 2, COUGH_EINVAL, "sample_rate = %d", cfg->sample_rate);
     const int n_mels = cfg->n_mels, n_mfcc = cfg->use_mfcc ? cfg->n_mfcc : 0;   // T.MFCC exists only with use_mfcc (:116-127)
     const double PI = 3.14159265358979323846;
-    std::vector<float> win(G_NFFT, 0.f), hann(G_NFFT), freqs(G_NFREQ), dct_t(size_t(n_mfcc) * n_mels), taps;
-    std::vector<float2> tw256(256), tw512(128);
+    std::vector<float> win(nfft, 0.f), hann(nfft), freqs(nfreq), dct_t(size_t(n_mfcc) * n_mels), taps;
+    std::vector<float2> tw256(256), tw512(128), twn(nfreq);
     std::vector<int> lo(n_mels), hi(n_mels), off(n_mels);
-    const int left = (G_NFFT - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
+    const int left = (nfft - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
     for (int n = 0; n < cfg->win_length; ++n) win[left + n] = window[n];
-    for (int n = 0; n < G_NFFT; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(G_NFFT)));
+    for (int n = 0; n < nfft; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(nfft)));
+    for (int k = 0; k < nfreq; ++k) {
+        const double a = -2.0 * PI * double(k) / double(nfft);
+        twn[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    }
     for (int jj = 0; jj < 16; ++jj)
         for (int k1 = 0; k1 < 16; ++k1) {
             const double a = -2.0 * PI * double(jj * k1) / 256.0;
@@ -417,7 +519,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     }
     for (int m = 0; m < n_mels; ++m) {   // CSR: the band's first .. last non-zero bin (zeros inside the range kept)
         int first = -1, last = -1;
-        for (int k = 0; k < G_NFREQ; ++k)
+        for (int k = 0; k < nfreq; ++k)
             if (mel_fb[k * n_mels + m] != 0.f) { if (first < 0) first = k; last = k; }
         if (first < 0) { first = 0; last = -1; }   // empty band: no taps, mel power 0
         lo[m] = first;
@@ -431,29 +533,31 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     if (dct_t.empty()) dct_t.push_back(0.f);
     {   // torch.linspace(0, sample_rate // 2, 257) in float32: start + step * i below the midpoint, end - step * (n - 1 - i) above
         const float end = float(cfg->sample_rate / 2);
-        const volatile float step = end / float(G_NFREQ - 1);
-        for (int i = 0; i < G_NFREQ; ++i) {
-            volatile float prod = i < G_NFREQ / 2 ? step * float(i) : step * float(G_NFREQ - i - 1);
-            freqs[i] = i < G_NFREQ / 2 ? prod : end - prod;
+        const volatile float step = end / float(nfreq - 1);
+        for (int i = 0; i < nfreq; ++i) {
+            volatile float prod = i < nfreq / 2 ? step * float(i) : step * float(nfreq - i - 1);
+            freqs[i] = i < nfreq / 2 ? prod : end - prod;
         }
     }
     // one device blob
-    size_t o_win = 0, o_hann = o_win + align256g(G_NFFT * 4), o_tw256 = o_hann + align256g(G_NFFT * 4),
-           o_tw512 = o_tw256 + align256g(256 * 8), o_lo = o_tw512 + align256g(128 * 8), o_hi = o_lo + align256g(n_mels * 4),
+    size_t o_win = 0, o_hann = o_win + align256g(nfft * 4), o_tw256 = o_hann + align256g(nfft * 4),
+           o_tw512 = o_tw256 + align256g(256 * 8), o_twn = o_tw512 + align256g(128 * 8), o_lo = o_twn + align256g(nfreq * 8),
+           o_hi = o_lo + align256g(n_mels * 4),
            o_off = o_hi + align256g(n_mels * 4), o_taps = o_off + align256g(n_mels * 4),
            o_dct = o_taps + align256g(taps.size() * 4), o_freqs = o_dct + align256g(dct_t.size() * 4),
-           total = o_freqs + align256g(G_NFREQ * 4);
+           total = o_freqs + align256g(nfreq * 4);
     std::vector<char> host(total, 0);
-    std::memcpy(host.data() + o_win, win.data(), G_NFFT * 4);
-    std::memcpy(host.data() + o_hann, hann.data(), G_NFFT * 4);
+    std::memcpy(host.data() + o_win, win.data(), nfft * 4);
+    std::memcpy(host.data() + o_hann, hann.data(), nfft * 4);
     std::memcpy(host.data() + o_tw256, tw256.data(), 256 * 8);
     std::memcpy(host.data() + o_tw512, tw512.data(), 128 * 8);
+    std::memcpy(host.data() + o_twn, twn.data(), nfreq * 8);
     std::memcpy(host.data() + o_lo, lo.data(), n_mels * 4);
     std::memcpy(host.data() + o_hi, hi.data(), n_mels * 4);
     std::memcpy(host.data() + o_off, off.data(), n_mels * 4);
     std::memcpy(host.data() + o_taps, taps.data(), taps.size() * 4);
     std::memcpy(host.data() + o_dct, dct_t.data(), dct_t.size() * 4);
-    std::memcpy(host.data() + o_freqs, freqs.data(), G_NFREQ * 4);
+    std::memcpy(host.data() + o_freqs, freqs.data(), nfreq * 4);
     GenFeat* g = new GenFeat();
     g->N = cfg->segment_samples;
     g->hop = cfg->hop_length;
@@ -461,6 +565,8 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     g->n_mels = n_mels;
     g->n_mfcc = n_mfcc;
     g->sample_rate = cfg->sample_rate;
+    g->nfft = nfft;
+    g->nfreq = nfreq;
     g->d_blob = nullptr;
     hipError_t e = hipMalloc(&g->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(g->d_blob, host.data(), total, hipMemcpyHostToDevice);
@@ -475,12 +581,24 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     g->win_full = reinterpret_cast<const float*>(b + o_hann);
     g->tw256 = reinterpret_cast<const float2*>(b + o_tw256);
     g->tw512 = reinterpret_cast<const float2*>(b + o_tw512);
+    g->twn = reinterpret_cast<const float2*>(b + o_twn);
     g->mel_lo = reinterpret_cast<const int*>(b + o_lo);
     g->mel_hi = reinterpret_cast<const int*>(b + o_hi);
     g->mel_off = reinterpret_cast<const int*>(b + o_off);
     g->mel_w = reinterpret_cast<const float*>(b + o_taps);
     g->dct_t = reinterpret_cast<const float*>(b + o_dct);
     g->freqs = reinterpret_cast<const float*>(b + o_freqs);
+    if (nfft != G_NFFT) {   // gen_stft_pow2_kernel: 4 waves x (two ping-pong buffers + a spectrum) of dynamic LDS, > 64 KB at 2048
+        const void* fns[] = {reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, false>),
+                             reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, true>),
+                             reinterpret_cast<const void*>(gen_stft_pow2_kernel<true, false>)};
+        for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(pow2_lds_bytes(2048))) != hipSuccess) {
+                set_error("cough_featurizer_create (generic geometry): hipFuncSetAttribute failed");
+                gen_feat_destroy(g);
+                return COUGH_EHIP;
+            }
+    }
     *out = g;
     return COUGH_OK;
 }
@@ -501,7 +619,7 @@ struct GenCarve {
 };
 GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
     GenCarve c;
-    const size_t spec = size_t(G_NFREQ) * g->T * 4, mel = size_t(g->n_mels) * g->T * 4;
+    const size_t spec = size_t(g->nfreq) * g->T * 4, mel = size_t(g->n_mels) * g->T * 4;
     const size_t per = spec * (contrast ? 2 : 0) + mel;   // the spectrograms exist only for the contrast rows
     size_t sub = G_SUB_BYTES / per;
     if (sub < 1) sub = 1;
@@ -526,15 +644,10 @@ int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, 
                     hipStream_t stream) {
     COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_spectrogram: row stride %lld < segment of %d samples", wav_stride, g->N);
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
-    const dim3 grid((g->T + G_FPB - 1) / G_FPB, n_clips), block(256);
     const float* win = full ? g->win_full : g->win;
     const GenMel none{0, nullptr, nullptr, nullptr, nullptr};
-    if (mag)
-        hipLaunchKernelGGL((gen_stft_kernel<true, false>), grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win,
-                           g->tw256, g->tw512, (const float*)nullptr, 0, 0.f, d_spec, none);
-    else
-        hipLaunchKernelGGL((gen_stft_kernel<false, false>), grid, block, 0, stream, d_wav, wav_stride, g->N, g->hop, g->T, win,
-                           g->tw256, g->tw512, (const float*)nullptr, 0, 0.f, d_spec, none);
+    if (mag) gen_launch_stft<true, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
+    else gen_launch_stft<false, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
@@ -562,11 +675,10 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         float* feat = d_feat + (long long)c0 * nfeat * T;
         const float* pk = normalize ? peaks : nullptr;
         if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, g->N, peaks);
-        const dim3 gs((T + G_FPB - 1) / G_FPB, nc), gt((T + G_TT - 1) / G_TT, nc);
+        const dim3 gt((T + G_TT - 1) / G_TT, nc);
         // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
         const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w}, none{0, nullptr, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL((gen_stft_kernel<false, true>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
-                           g->tw256, g->tw512, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm);
+        gen_launch_stft<false, true>(g, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
         hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
                            g->dct_t, feat, nfeat);
@@ -577,11 +689,9 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         }
         if (want_contrast) {
             // from the un-emphasised (normalised) signal (:476-478)
-            hipLaunchKernelGGL((gen_stft_kernel<false, false>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T, g->win,
-                               g->tw256, g->tw512, pk, 0, 0.f, P, none);
-            hipLaunchKernelGGL((gen_stft_kernel<true, false>), gs, dim3(256), 0, stream, w, wav_stride, g->N, g->hop, T,
-                               g->win_full, g->tw256, g->tw512, pk, 0, 0.f, M, none);
-            hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, contrast, g->freqs,
+            gen_launch_stft<false, false>(g, w, wav_stride, nc, g->win, pk, 0, 0.f, P, none, stream);
+            gen_launch_stft<true, false>(g, w, wav_stride, nc, g->win_full, pk, 0, 0.f, M, none, stream);
+            hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, g->nfreq, contrast, g->freqs,
                                float(g->sample_rate) / 2.0f, feat, nfeat, nbase);
             hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
         }

@@ -13,10 +13,10 @@ Differences a caller can observe:
   ``(B, F, T)`` with the reference's per-clip reduction semantics; like the reference it takes a waveform of ANY
   length N (T = 1 + N // hop_length): ``segment_samples`` runs on the tuned kernel, other lengths on the generic chain.
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
-  spectral contrast + centroid) for every geometry at ``n_fft=512``: any ``sample_rate`` / ``hop_length`` /
-  ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The shipped geometry
-  runs on the tuned one-launch kernel, the others on a chain of small kernels (``csrc/featurize_generic.hip``);
-  ``n_fft != 512`` raises ``ValueError``.
+  spectral contrast + centroid) for every geometry with a power-of-two ``n_fft`` (64..2048): any ``sample_rate`` /
+  ``hop_length`` / ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The
+  shipped geometry runs on the tuned one-launch kernel, the others on a chain of small kernels
+  (``csrc/featurize_generic.hip``); another ``n_fft`` raises ``ValueError``.
 * ``use_spectral_contrast=True`` with 5 or more bands (the constructor default is 6) yields NaN rows exactly as
   the reference does (its first band is one bin wide, ``src/preprocessing.py:272-290``); a warning says so.
 """
@@ -91,10 +91,11 @@ class AudioPreprocessor:
                           "bin wide); this implementation reproduces them. Use use_spectral_contrast=False (the "
                           "shipped configuration, src/train.py:264-287) or n_contrast_bands <= 4.", stacklevel=2)
         # Geometry: the tuned one-kernel path serves the shipped 16 kHz / 512 / 160 / 400 / 64 mel / 13 MFCC / 1 s layout with
-        # f_max <= sample_rate / 4; every other geometry at n_fft = 512 runs on the generic kernel chain
+        # f_max <= sample_rate / 4; every other geometry (n_fft a power of two) runs on the generic kernel chain
         # (csrc/featurize_generic.hip) -- the library picks.  What torch / torchaudio would refuse is refused here too.
-        if n_fft != 512:
-            raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements n_fft=512")
+        if not (64 <= n_fft <= 2048 and n_fft & (n_fft - 1) == 0):
+            raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements the powers of two 64..2048 "
+                             "(512, the reference's default, on the register FFT kernels)")
         if not 1 <= win_length <= n_fft:
             raise ValueError(f"AudioPreprocessor: win_length={win_length} must lie in 1..n_fft (torch.stft)")
         if hop_length < 1:

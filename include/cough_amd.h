@@ -44,15 +44,16 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
 /* ------------------------------------------------------------------ featuriser (K1)
  * Replaces AudioPreprocessor.__init__ / extract_features / normalize
  * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for every flag of the
- * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry at
- * n_fft = 512: any sample_rate, hop_length >= 1, win_length <= 512, n_mels <= 128, n_mfcc <= n_mels,
- * any filterbank (f_min / f_max), any segment longer than 256 samples (RealtimePreprocessor's
+ * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry with a
+ * power-of-two n_fft (64 .. 2048): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 128,
+ * n_mfcc <= n_mels, any filterbank (f_min / f_max), any segment longer than n_fft / 2 samples (RealtimePreprocessor's
  * window_duration, :559-580; the engine's re-construction from a checkpoint config,
  * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry,
  * which (with a filterbank of <= 8 taps per band below bin 128, i.e. f_max <= sample_rate / 4) runs on
  * the tuned one-launch kernel; every other geometry runs on a chain of small kernels and NEEDS A
- * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft != 512 returns
- * COUGH_EUNSUPPORTED.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
+ * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft = 512 (the reference's
+ * default) uses the register radix-16 x radix-16 FFT, the other powers of two a radix-2 Stockham kernel; an n_fft
+ * that is not a power of two returns COUGH_EUNSUPPORTED.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
  * (log-mel or PCEN), MFCC, delta, (delta-delta), (spectral contrast + centroid). */
 #define COUGH_MAX_CONTRAST_BANDS 16
 typedef struct cough_feat_config {
@@ -105,9 +106,9 @@ size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
 int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,
                        int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Stand-alone STFT: T.Spectrogram(n_fft=512, win_length, hop_length, power=2.0) of
+/* Stand-alone STFT: T.Spectrogram(n_fft, win_length, hop_length, power=2.0) of
  * /root/reference/src/preprocessing.py:131-136 (the "STFT stage" on its own; cough_featurize never
- * materialises it) at the featuriser's geometry.  d_spec: [n_clips][n_fft/2+1 = 257][num_frames] float32
+ * materialises it) at the featuriser's geometry.  d_spec: [n_clips][n_fft/2+1][num_frames] float32
  * (shipped: 101 frames, the persistent kernel the 50 % HBM figure is quoted on).
  * flags: COUGH_SPEC_MAGNITUDE -> power=1.0; COUGH_SPEC_FULL_WINDOW -> periodic Hann(n_fft) instead of the
  * featuriser's window (both together = the spectrogram T.SpectralCentroid(sample_rate, n_fft, hop_length)

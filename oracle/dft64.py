@@ -12,43 +12,44 @@ import numpy as np
 SR, N_FFT, HOP, WIN, N_MELS, N_MFCC = 16000, 512, 160, 400, 64, 13
 
 
-def window512(win: int = WIN) -> np.ndarray:
+def window512(win: int = WIN, n_fft: int = N_FFT) -> np.ndarray:
     n = np.arange(win, dtype=np.float64)
     w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win)          # periodic Hann
-    out = np.zeros(N_FFT)
-    left = (N_FFT - win) // 2
+    out = np.zeros(n_fft)
+    left = (n_fft - win) // 2
     out[left:left + win] = w
     return out
 
 
-def frames(x: np.ndarray, hop: int = HOP) -> np.ndarray:
-    """(N,) -> (T, 512) reflect-padded, T = 1 + N // hop."""
+def frames(x: np.ndarray, hop: int = HOP, n_fft: int = N_FFT) -> np.ndarray:
+    """(N,) -> (T, n_fft) reflect-padded, T = 1 + N // hop."""
     x = np.asarray(x, dtype=np.float64)
-    pad = N_FFT // 2
+    pad = n_fft // 2
     xp = np.concatenate([x[1:pad + 1][::-1], x, x[-pad - 1:-1][::-1]])
     t = 1 + len(x) // hop
-    idx = np.arange(N_FFT)[None, :] + hop * np.arange(t)[:, None]
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(t)[:, None]
     return xp[idx]
 
 
-def stft_power(x: np.ndarray, hop: int = HOP, win: int = WIN) -> np.ndarray:
-    """(N,) -> (257, T)."""
-    f = frames(x, hop) * window512(win)[None, :]
+def stft_power(x: np.ndarray, hop: int = HOP, win: int = WIN, n_fft: int = N_FFT) -> np.ndarray:
+    """(N,) -> (n_fft // 2 + 1, T)."""
+    f = frames(x, hop, n_fft) * window512(win, n_fft)[None, :]
     s = np.fft.rfft(f, axis=1)
     return (s.real ** 2 + s.imag ** 2).T
 
 
-def mel_fb(f_min: float = 100.0, f_max: float = 4000.0, n_mels: int = N_MELS, sample_rate: int = SR) -> np.ndarray:
-    """(257, n_mels) HTK triangles, no area normalisation."""
+def mel_fb(f_min: float = 100.0, f_max: float = 4000.0, n_mels: int = N_MELS, sample_rate: int = SR,
+           n_fft: int = N_FFT) -> np.ndarray:
+    """(n_fft // 2 + 1, n_mels) HTK triangles, no area normalisation."""
     def hz2mel(f):
         return 2595.0 * np.log10(1.0 + f / 700.0)
 
     def mel2hz(m):
         return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
 
-    freqs = np.linspace(0.0, sample_rate // 2, N_FFT // 2 + 1)
+    freqs = np.linspace(0.0, sample_rate // 2, n_fft // 2 + 1)
     pts = mel2hz(np.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2))
-    fb = np.zeros((N_FFT // 2 + 1, n_mels))
+    fb = np.zeros((n_fft // 2 + 1, n_mels))
     for m in range(n_mels):
         lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
         rise = (freqs - lo) / (ce - lo)
@@ -67,9 +68,9 @@ def dct_ortho(n_mfcc: int = N_MFCC, n_mels: int = N_MELS) -> np.ndarray:
 
 
 def features(x: np.ndarray, sample_rate: int = SR, n_mels: int = N_MELS, hop: int = HOP, win: int = WIN,
-             f_min: float = 100.0, f_max: float = 4000.0, n_mfcc: int = N_MFCC) -> np.ndarray:
+             f_min: float = 100.0, f_max: float = 4000.0, n_mfcc: int = N_MFCC, n_fft: int = N_FFT) -> np.ndarray:
     """(N,) float -> (n_mels + 2 n_mfcc, T) float64: mel rows, z-scored MFCC, delta.  Defaults: (16000,) -> (90, 101)."""
-    mel = mel_fb(f_min, f_max, n_mels, sample_rate).T @ stft_power(x, hop, win)   # (n_mels, T)
+    mel = mel_fb(f_min, f_max, n_mels, sample_rate, n_fft).T @ stft_power(x, hop, win, n_fft)   # (n_mels, T)
     db = 10.0 * np.log10(np.maximum(mel, 1e-10))
     db = np.maximum(db, db.max() - 80.0)
     mel_n = np.clip((db + 80.0) / 80.0, 0.0, 1.0)

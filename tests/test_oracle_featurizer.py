@@ -34,7 +34,8 @@ def test_filterbank_against_transformers_and_float64():
 
 
 def _third_party_features(wav: np.ndarray, sample_rate: int = 16000, n_mels: int = 64, hop_length: int = 160,
-                          win_length: int = 400, f_min: float = 100.0, f_max: float = 4000.0, n_mfcc: int = 13) -> np.ndarray:
+                          win_length: int = 400, f_min: float = 100.0, f_max: float = 4000.0, n_mfcc: int = 13,
+                          n_fft: int = 512) -> np.ndarray:
     """The (n_mels + 2 n_mfcc) x T feature image (shipped: 90x101) computed WITHOUT any code of this repo:
     transformers.audio_utils (window_function, mel_filter_bank, spectrogram with its own framing / FFT / mel projection /
     power_to_db / db_range) + scipy's DCT + numpy for the z-score and the delta.  transformers frames `frame_length =
@@ -45,8 +46,8 @@ def _third_party_features(wav: np.ndarray, sample_rate: int = 16000, n_mels: int
     from scipy.fft import dct
     assert win_length % 2 == 0
     win = tr.window_function(win_length, "hann", periodic=True)
-    fb = tr.mel_filter_bank(257, n_mels, f_min, f_max, sample_rate, norm=None, mel_scale="htk")
-    db = tr.spectrogram(wav.astype(np.float64), window=win, frame_length=win_length, hop_length=hop_length, fft_length=512,
+    fb = tr.mel_filter_bank(n_fft // 2 + 1, n_mels, f_min, f_max, sample_rate, norm=None, mel_scale="htk")
+    db = tr.spectrogram(wav.astype(np.float64), window=win, frame_length=win_length, hop_length=hop_length, fft_length=n_fft,
                         power=2.0, center=True, pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB",
                         reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64)   # (n_mels, T) dB, per-clip 80 dB floor
     assert db.shape == (n_mels, 1 + len(wav) // hop_length)
@@ -114,6 +115,9 @@ GEOMETRIES = {     # AudioPreprocessor(...) constructor calls the generic HIP pa
     "two_seconds": dict(segment_duration=2.0),
     "hop128_win512": dict(hop_length=128, win_length=512),
     "sr22050": dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441),
+    "nfft256": dict(n_fft=256, win_length=256, hop_length=128),
+    "nfft1024_win400": dict(n_fft=1024),
+    "nfft2048_sr44100": dict(n_fft=2048, win_length=2048, hop_length=512, sample_rate=44100, f_max=16000.0, n_mels=128),
 }
 
 
@@ -124,13 +128,13 @@ def geometry_clip(seed: int, n: int) -> np.ndarray:
 
 
 @pytest.mark.parametrize("name", ["mels40_fmax8k", "mels80_mfcc20", "mels128_mfcc40_fmin20", "half_second", "two_seconds",
-                                  "hop128_win512"])
+                                  "hop128_win512", "nfft256", "nfft1024_win400", "nfft2048_sr44100"])
 def test_generic_geometry_restatement_against_third_party_code(name):
     """The restatement at the constructor's OTHER geometries against transformers + scipy (code the builder did not write):
     the parameters n_mels / n_mfcc / f_min / f_max / hop / win / segment length are honoured the way independent code
     honours them."""
     g = dict(sample_rate=16000, n_mels=64, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13,
-             segment_duration=1.0)
+             segment_duration=1.0, n_fft=512)
     g.update(GEOMETRIES[name])
     n = int(g["sample_rate"] * g.pop("segment_duration"))
     worst_mel = worst_rest = 0.0
@@ -150,14 +154,14 @@ def test_generic_geometry_restatement_against_third_party_code(name):
 def test_generic_geometry_restatement_against_float64(name):
     """The float32 restatement at non-default constructor geometries vs the independent float64 re-derivation."""
     g = dict(sample_rate=16000, n_mels=64, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13,
-             segment_duration=1.0)
+             segment_duration=1.0, n_fft=512)
     g.update(GEOMETRIES[name])
     n = int(g["sample_rate"] * g.pop("segment_duration"))
     for seed in (0, 3, 4):
         x = geometry_clip(seed, n)
         f32 = F.extract_features(torch.from_numpy(x)[None], **F.geometry_kwargs(**g))[0].numpy()
         f64 = dft64.features(x, g["sample_rate"], g["n_mels"], g["hop_length"], g["win_length"], g["f_min"], g["f_max"],
-                             g["n_mfcc"])
+                             g["n_mfcc"], g["n_fft"])
         nm = g["n_mels"]
         assert f32.shape == f64.shape == (nm + 2 * g["n_mfcc"], 1 + n // g["hop_length"])
         assert np.abs(f32[:nm] - f64[:nm]).max() < 2e-5      # float32 filterbank taps differ from float64 ones by 1e-5
