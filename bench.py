@@ -254,6 +254,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1 and numa["pci"] is not None:
+        # the sysfs order may not be the runtime's: check the PCI address of the device this rank really got
+        from cough_detector_amd.hostcpu import rebind_to_pci_numa
+        props = torch.cuda.get_device_properties(dev)
+        if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            numa = rebind_to_pci_numa(f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0", numa)
     dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -453,8 +459,8 @@ def main():
             line["collectives"] = {"started": min(r["collectives_started"] for r in rank_records),
                                    "finished": min(r["collectives_finished"] for r in rank_records),
                                    "per": f"{args.gather_every} steps", "skipped": skip_gather}
-            line["numa_binding"] = ({"pci": numa["pci"], "numa_node": numa["numa_node"], "cpus": numa["cpus"]}
-                                    if world > 1 else None)
+            line["numa_binding"] = ({"pci": numa["pci"], "numa_node": numa["numa_node"], "cpus": numa["cpus"],
+                                     "rebound_after_init": numa.get("rebound", False)} if world > 1 else None)
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

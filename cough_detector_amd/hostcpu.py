@@ -142,7 +142,7 @@ def bind_to_gpu_numa(local_rank: int, node_root: str = "/sys/devices/system/node
     try:
         with open(os.path.join(node_root, f"node{node}", "cpulist")) as f:
             want = _parse_cpulist(f.read())
-        allowed = want & os.sched_getaffinity(0)
+        allowed = want & _initial_affinity()
         if not allowed:
             return info
         os.sched_setaffinity(0, allowed)
@@ -150,3 +150,45 @@ def bind_to_gpu_numa(local_rank: int, node_root: str = "/sys/devices/system/node
     except (OSError, ValueError):
         pass
     return info
+
+
+def rebind_to_pci_numa(pci: str, info: dict, node_root: str = "/sys/devices/system/node",
+                       pci_root: str = "/sys/bus/pci/devices") -> dict:
+    """After the runtime is up: ``pci`` is the address of the device this rank REALLY got (from the device properties).
+    When it differs from what ``bind_to_gpu_numa`` derived from sysfs order (an enumeration the runtime re-ordered), bind
+    again to the NUMA node of the real device.  Threads created in between keep the first binding; the launch thread and
+    everything created later move.  Returns the updated record (``rebound`` says whether anything changed)."""
+    info = dict(info)
+    info["rebound"] = False
+    if not pci or pci == info.get("pci") or not hasattr(os, "sched_setaffinity"):
+        return info
+    try:
+        with open(os.path.join(pci_root, pci, "numa_node")) as f:
+            node = int(f.read().strip())
+        info["pci"] = pci
+        if node < 0:
+            return info
+        with open(os.path.join(node_root, f"node{node}", "cpulist")) as f:
+            want = _parse_cpulist(f.read())
+        # the first binding may have narrowed the affinity to another node: widen from the process-wide mask of pid 1's view
+        allowed = want & _initial_affinity()
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            info.update(numa_node=node, cpus=len(allowed), rebound=True)
+    except (OSError, ValueError):
+        pass
+    return info
+
+
+_AFFINITY0 = None
+
+
+def _initial_affinity() -> set:
+    """The affinity mask this process started with (remembered at import, before any binding narrows it)."""
+    return set(_AFFINITY0) if _AFFINITY0 is not None else set(os.sched_getaffinity(0))
+
+
+try:
+    _AFFINITY0 = frozenset(os.sched_getaffinity(0))
+except (AttributeError, OSError):
+    _AFFINITY0 = None

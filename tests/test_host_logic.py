@@ -252,6 +252,33 @@ def test_bind_to_gpu_numa_sets_the_affinity_of_the_node(tmp_path):
         os.sched_setaffinity(0, before)
 
 
+def test_rebind_to_the_numa_node_of_the_device_the_runtime_really_gave(tmp_path):
+    """bench.py checks the PCI address of its device after init: a rank that was bound by sysfs order to the wrong GPU's
+    NUMA node moves to the right one (and the first binding must not have narrowed what it may move to)."""
+    from cough_detector_amd import hostcpu
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no affinity call on this platform")
+    before = os.sched_getaffinity(0)
+    cpus = sorted(before)
+    if len(cpus) < 2:
+        pytest.skip("needs two CPUs")
+    lo, hi = cpus[:len(cpus) // 2], cpus[len(cpus) // 2:]
+    sysfs, numa = _fake_node(tmp_path, [(128, "0000:05:00.0", 0), (129, "0000:85:00.0", 1)])
+    for k, half in ((0, lo), (1, hi)):
+        (numa / f"node{k}").mkdir(parents=True)
+        (numa / f"node{k}" / "cpulist").write_text(",".join(str(c) for c in half) + "\n")
+    try:
+        info = hostcpu.bind_to_gpu_numa(0, node_root=str(numa), environ={}, **sysfs)
+        assert info["numa_node"] == 0 and os.sched_getaffinity(0) == set(lo)
+        same = hostcpu.rebind_to_pci_numa("0000:05:00.0", info, node_root=str(numa), pci_root=str(tmp_path / "pci"))
+        assert same["rebound"] is False and os.sched_getaffinity(0) == set(lo)
+        moved = hostcpu.rebind_to_pci_numa("0000:85:00.0", info, node_root=str(numa), pci_root=str(tmp_path / "pci"))
+        assert moved["rebound"] is True and moved["numa_node"] == 1 and moved["pci"] == "0000:85:00.0"
+        assert os.sched_getaffinity(0) == set(hi)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_effective_dtype_reports_the_kernels_that_run():
     """A reduced-precision request the compiled kernels do not cover is reported (and warned about at the first
     forward, tests/test_gpu_fuzz.py), not silently replaced."""
