@@ -58,3 +58,30 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
     pipe(w.cuda(), events=ev)
     torch.cuda.synchronize()
     assert 0.0 < ev[0].elapsed_time(ev[1]) < 50.0
+
+
+@pytest.mark.parametrize("flags,rows", [(dict(use_delta_delta=True), 103),
+                                        (dict(use_delta_delta=True, use_pre_emphasis=True, use_pcen=True,
+                                              use_spectral_contrast=True, n_contrast_bands=4), 108)])
+def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(resnet_heights_golden, flags, rows):
+    """waveform -> logits in one C-ABI call when the stem cannot be fused (delta-delta / PCEN / contrast rows): features are
+    materialised in the workspace, the 103-row image runs on the split-bf16 kernels compiled for it (108 rows: stem x3,
+    blocks exact f32), and the logits match featurise + CPU oracle classifier."""
+    import warnings
+    sd, _ = resnet_heights_golden["h103"]
+    w = synth_batch(900, 21, peak_normalize=False) * 0.5
+    kw = {**SHIPPED, **flags}
+    pre = cda.AudioPreprocessor(device="cuda", **kw)
+    model = cda.create_model("residual", n_mels=rows, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    pipe = cda.CoughPipeline(pre, model.cuda())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, feats = pipe(w.cuda(), normalize=True, return_features=True)
+    assert feats.shape == (21, rows, 101) and model.effective_dtype(rows, 101) == ("bf16x3" if rows == 103 else "fp32")
+    ref_feats = ofeat.extract_features_batch(w, normalize_first=True, **kw)
+    ref = ores.forward(ref_feats.unsqueeze(1), sd)
+    err = (logits.cpu() - ref).abs().max().item()
+    print(f"{rows}-row pipeline: logits max abs err {err:.2e}")
+    assert err < LOGIT_TOL
+    assert torch.equal(pipe(w.cuda(), normalize=True), logits)
