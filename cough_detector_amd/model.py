@@ -236,11 +236,15 @@ class CoughDetectorResidual(nn.Module):
             return self.compute_dtype
         if self.channels != (32, 64, 128):
             return "fp32"
-        if self.compute_dtype == "bf16x3" and (height, width) not in self.X3_IMAGES:
-            return "fp32"
+        if self.compute_dtype == "bf16x3":
+            # the kernels are selected by the block-0 input (stem + pool output), csrc/resnet.hip rbx_compiled():
+            # 22x25 <- 87..90 rows, 26x25 <- 103..106, 27x25 <- 107..110, each x 99..102 frames
+            p1 = (((height - 1) // 2 + 1) // 2, ((width - 1) // 2 + 1) // 2)
+            if p1 not in self.X3_BLOCK_INPUTS:
+                return "fp32"
         return self.compute_dtype
 
-    X3_IMAGES = ((90, 101), (103, 101), (110, 101))     # csrc/resnet.hip rbx_compiled()
+    X3_BLOCK_INPUTS = ((22, 25), (26, 25), (27, 25))
 
     def _warn_fallback(self, height: int, width: int) -> None:
         eff = self.effective_dtype(height, width)

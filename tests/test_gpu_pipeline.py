@@ -65,8 +65,8 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
                                               use_spectral_contrast=True, n_contrast_bands=4), 108)])
 def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(resnet_heights_golden, flags, rows):
     """waveform -> logits in one C-ABI call when the stem cannot be fused (delta-delta / PCEN / contrast rows): features are
-    materialised in the workspace, the 103-row image runs on the split-bf16 kernels compiled for it (108 rows: stem x3,
-    blocks exact f32), and the logits match featurise + CPU oracle classifier."""
+    materialised in the workspace, the 103- and 108-row images run on the split-bf16 kernels (block inputs 26x25 / 27x25),
+    and the logits match featurise + CPU oracle classifier."""
     import warnings
     sd, _ = resnet_heights_golden["h103"]
     w = synth_batch(900, 21, peak_normalize=False) * 0.5
@@ -78,7 +78,7 @@ def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(re
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         logits, feats = pipe(w.cuda(), normalize=True, return_features=True)
-    assert feats.shape == (21, rows, 101) and model.effective_dtype(rows, 101) == ("bf16x3" if rows == 103 else "fp32")
+    assert feats.shape == (21, rows, 101) and model.effective_dtype(rows, 101) == "bf16x3"
     ref_feats = ofeat.extract_features_batch(w, normalize_first=True, **kw)
     ref = ores.forward(ref_feats.unsqueeze(1), sd)
     err = (logits.cpu() - ref).abs().max().item()
