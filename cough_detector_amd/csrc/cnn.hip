@@ -482,7 +482,8 @@ struct CnnX3Args {
 template <int CIN, int NT, int MW, bool POOL, int WM, int WN, int PIECES>
 __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args a) {
     constexpr int QP = CIN / 4, KSTEPS = 9 * CIN / 16, S = POOL ? 2 : 1, THREADS = 64 * WM * WN, NTW = NT / WN;
-    constexpr int UNP = (PIECES + THREADS - 1) / THREADS;   // 16-byte pieces per thread
+    constexpr int NPIECES = PIECES < 0 ? -PIECES : PIECES;   // (a negative PIECES selects the LEAN fragment pipeline)
+    constexpr int UNP = (NPIECES + THREADS - 1) / THREADS;   // 16-byte pieces per thread
     static_assert(NT % WN == 0, "channel tiles split evenly over the N-waves");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -555,8 +556,13 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
 
     const bf16_t* wl = a.wf + (size_t(nt0) * 2) * 512 + lane * 8;
     const size_t wstep = size_t(a.ntot) * 2 * 512;
-    constexpr int D = (NTW <= 2) ? 4 : 2;
-    bf16x8 wring[D][NTW][2], af[2][MW][2];
+    // activation fragments: a whole k-step of tiles ahead (af[2][MW]: 2 * MW * 8 registers), or -- LEAN -- ONE tile ahead
+    // through two rotating sets (16 registers) and a 2-deep weight ring: with MW = 5 that is what brings the kernel under the
+    // 168 registers of THREE waves per SIMD, i.e. three workgroups per CU whose staging / MFMA phases interleave
+    constexpr bool LEAN = PIECES < 0;
+    constexpr int D = LEAN ? 2 : (NTW <= 2) ? 4 : 2;
+    constexpr int AFN = LEAN ? 1 : MW;
+    bf16x8 wring[D][NTW][2], af[2][AFN][2];
     auto wload = [&](int s, bf16x8 (&dst)[NTW][2]) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -572,24 +578,39 @@ __global__ __launch_bounds__(64 * WM * WN) void cnn_conv_lds_x3_kernel(CnnX3Args
     };
 #pragma unroll
     for (int i = 0; i < D; ++i) wload(i, wring[i]);
+    if constexpr (LEAN) {
+        aload(std::integral_constant<int, 0>{}, 0, af[0][0]);
+    } else {
 #pragma unroll
-    for (int mt = 0; mt < MW; ++mt) aload(std::integral_constant<int, 0>{}, mt, af[0][mt]);
+        for (int mt = 0; mt < MW; ++mt) aload(std::integral_constant<int, 0>{}, mt, af[0][mt]);
+    }
     auto step = [&]<int s>() {
         bf16x8 bw[NTW][2];
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) { bw[nt][0] = wring[s % D][nt][0]; bw[nt][1] = wring[s % D][nt][1]; }
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
-            if constexpr (s + 1 < KSTEPS) aload(std::integral_constant<int, s + 1>{}, mt, af[(s + 1) & 1][mt]);
+            bf16x8 cur0, cur1;
+            if constexpr (LEAN) {
+                const int slot = (s * MW + mt) & 1;      // compile-time after unrolling
+                cur0 = af[slot][0][0];
+                cur1 = af[slot][0][1];
+                if (mt + 1 < MW) aload(std::integral_constant<int, s>{}, mt + 1, af[slot ^ 1][0]);
+                else if constexpr (s + 1 < KSTEPS) aload(std::integral_constant<int, s + 1>{}, 0, af[slot ^ 1][0]);
+            } else {
+                cur0 = af[s & 1][mt][0];
+                cur1 = af[s & 1][mt][1];
+                if constexpr (s + 1 < KSTEPS) aload(std::integral_constant<int, s + 1>{}, mt, af[(s + 1) & 1][mt]);
+            }
             if constexpr (s + D < KSTEPS) {
                 if (mt == 0) wload(s + D, wring[s % D]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][0], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][1], bw[nt][0], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt][0], bw[nt][1], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur0, bw[nt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur1, bw[nt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur0, bw[nt][1], acc[mt][nt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -762,9 +783,10 @@ int cnn_upload(void** dst, const std::vector<T>& v) {
 struct X3Cfg { int nt, mw, wm, wn, pieces; };
 #ifndef CNN_X3_CFG32
 // measured (profiles/r04_cnn_x3_experiments.txt): 4-wave workgroups of 2 x 2 waves with bands small enough for TWO per CU
-// (one's staging overlaps the other's MFMA phase) for the 32- and 64-channel inputs; the 128-channel input (one clip =
+// (one's staging overlaps the other's MFMA phase) for the 64-channel input and THREE (lean fragment pipeline) for the
+// 32-channel one; the 128-channel input (one clip =
 // 120 GEMM rows, 86 KB of images: one workgroup per CU) as 2 x 4 waves so that all eight waves have rows
-#define CNN_X3_CFG32 2, 5, 2, 2, 5056
+#define CNN_X3_CFG32 2, 5, 2, 2, -3328   /* negative: LEAN fragment pipeline, <= 168 registers, bands <= 52 KB: THREE workgroups per CU */
 #define CNN_X3_CFG64 4, 3, 2, 2, 5056
 #define CNN_X3_CFG128 4, 2, 2, 4, 6144
 #endif
@@ -786,7 +808,7 @@ inline int x3_band(const cough_cnn::Layer& l, const CnnShape& s, int in_w) {
     const int per_out = l.pool == 2 ? 4 : 1;
     int band = (c->wm * c->mw * 32) / (per_out * s.w);
     if (band > s.h) band = s.h;
-    while (band >= 1 && size_t((l.pool == 2 ? 2 : 1) * band + 2) * (in_w + 2) * (l.cin / 4) > size_t(c->pieces)) --band;
+    while (band >= 1 && size_t((l.pool == 2 ? 2 : 1) * band + 2) * (in_w + 2) * (l.cin / 4) > size_t(c->pieces < 0 ? -c->pieces : c->pieces)) --band;
     return band;
 }
 template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
@@ -797,10 +819,10 @@ void x3_launch(bool pool, dim3 grid, size_t lds, hipStream_t st, const CnnX3Args
 template <int CIN, int NT, int MW, int WM, int WN, int PIECES>
 hipError_t x3_set_lds() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, true, WM, WN, PIECES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (PIECES < 0 ? -PIECES : PIECES) * 16 + 64);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_conv_lds_x3_kernel<CIN, NT, MW, false, WM, WN, PIECES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PIECES * 16 + 64);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (PIECES < 0 ? -PIECES : PIECES) * 16 + 64);
     return e;
 }
 
