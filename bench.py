@@ -21,7 +21,9 @@ Before ``--warmup`` an untimed pre-warm (``--prewarm-s``, default 0.6 s of the s
 the same as a long one.
 
 Extra objects on that line: ``roofline`` (featurise kernel vs HBM: algorithmic bytes per clip over the kernel's
-HIP-event time inside the timed region), ``roofline_classifier`` (algorithmic 35.67 MFLOP/clip of the residual blocks
+HIP-event time inside the timed region; ``traffic`` = HBM-side bytes per launch COLLECTED IN THIS RUN by two child runs of
+this script under ``rocprofv3 --pmc`` (FETCH_SIZE, WRITE_SIZE; ~4 s; ``--no-live-pmc`` or a missing rocprofv3 falls back to
+the committed record and says so in ``traffic_source``)), ``roofline_classifier`` (algorithmic 35.67 MFLOP/clip of the residual blocks
 vs the dense bf16 MFMA peak; the split-bf16 scheme issues 3 MFMAs per algorithmic one, reported as ``mfma_issue_frac``),
 ``roofline_stft`` (the STFT stage on its own) and ``cpu_baseline`` (the torch-CPU oracle timed on this box's host
 cores on a bounded sample; rank 0, N = 1 only).
@@ -78,6 +80,54 @@ def measured_pmc(batch: int, variant: str) -> dict:
         except (OSError, KeyError, ValueError):
             pass
     return {}
+
+
+def live_pmc_traffic(args, kernels=("featurize_kernel", "stft3_kernel")):
+    """HBM-side bytes per launch of the dominant kernel (and of the stand-alone STFT kernel), COLLECTED NOW: two child runs of this script under
+    ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE -- separate passes, counters only, no tracing; the program itself after
+    ``--``), corrected as MI355X_MICROARCH.md prescribes for gfx950 (both in KiB; FETCH_SIZE counts half the bytes of a
+    coalesced stream).  Children, never an exec: this process has initialised the GPU.  Returns
+    ``{kernel: {"traffic": bytes, "fetch": .., "write": .., "launches": n}}`` for the kernels that ran, or ``None`` (no
+    rocprofv3, a pass failed or timed out) -- the caller then falls back to the committed record."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--prewarm-s", "0",
+             "--batch", str(args.batch), "--dtype", args.dtype, "--no-live-pmc"] + (["--featurize-only"] if args.featurize_only else [])
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="cough_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("WORLD_SIZE", None)
+            try:
+                subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp",
+                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            except (subprocess.SubprocessError, OSError):
+                return None
+            vals = {k: [] for k in kernels}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") != counter:
+                            continue
+                        for k in kernels:
+                            if k in r.get("Kernel_Name", ""):
+                                vals[k].append(float(r["Counter_Value"]))
+            got[counter] = {k: (sum(v) / len(v), len(v)) for k, v in vals.items() if v}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k in kernels:
+        if k in got.get("FETCH_SIZE", {}) and k in got.get("WRITE_SIZE", {}):
+            fetch_b, write_b = got["FETCH_SIZE"][k][0] * 1024 * 2, got["WRITE_SIZE"][k][0] * 1024
+            res[k] = {"traffic": int(fetch_b + write_b), "fetch": int(fetch_b), "write": int(write_b),
+                      "launches": got["FETCH_SIZE"][k][1]}
+    return res or None
 
 
 def stft_stage(pre, batches, launches: int = 210) -> dict:
@@ -216,6 +266,8 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-s", type=float, default=0.6, help="untimed GPU pre-warm before --warmup (seconds)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: steps per all-gather of logits (one bucketed exchange per this many steps)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect roofline.traffic with rocprofv3 --pmc child runs (N = 1); use the committed PMC record")
     ap.add_argument("--total-clips", type=int, default=0,
                     help="configs[3]: one pass over a stream of this many distinct clips (all ranks together); "
                          "overrides --steps and --rotate")
@@ -395,8 +447,17 @@ def main():
         achieved = Bk * k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         pmc = measured_pmc(Bk, ("k1_fused_" + args.dtype) if fused else "k1")
         traffic, traffic_src = pmc.get("traffic_bytes_per_launch"), pmc.get("source")
+        live_all = None
         if traffic is not None:
             traffic = int(traffic)
+        if (world == 1 and not dist and not args.no_live_pmc and args.total_clips == 0 and Bk == B
+                and os.environ.get("COUGH_BENCH_LIVE_PMC", "1") == "1"):
+            live_all = live_pmc_traffic(args)
+            live = (live_all or {}).get("featurize_kernel")
+            if live is not None:
+                traffic = live["traffic"]
+                traffic_src = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child runs of this command, {live['launches']} launches "
+                               f"each): FETCH_SIZE[KiB]*1024*2 + WRITE_SIZE[KiB]*1024 = {live['fetch']} + {live['write']} bytes per launch")
         if args.featurize_only:
             workload = "configs[1]: batch=4096 synthetic 1s@16kHz mono -> 90x101 features, f32"
         elif args.total_clips > 0:
@@ -449,6 +510,13 @@ def main():
         stft_in = [b_ for b_ in batches[:8] if b_.shape[0] == B]
         if world == 1 and not dist and stft_in:
             line["roofline_stft"] = stft_stage(pre, stft_in)
+            lv = (live_all or {}).get("stft3_kernel")
+            if lv is not None:     # the child runs launched the stand-alone STFT kernel too: its traffic from the same passes
+                rs = line["roofline_stft"]
+                rs["traffic"] = lv["traffic"]
+                rs["traffic_source"] = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ({lv['launches']} launches): "
+                                        f"{lv['fetch']} + {lv['write']} bytes per launch")
+                rs["traffic_over_algorithmic"] = round(lv["traffic"] / rs["algorithmic_bytes_per_launch"], 3)
         if world == 1 and not dist and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if dist:

@@ -23,7 +23,7 @@ def _run(monkeypatch, capsys, *argv):
 
 def test_default_line_has_every_contract_field(monkeypatch, capsys):
     d = _run(monkeypatch, capsys, "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "512", "--cpu-seconds", "1.0",
-             "--prewarm-s", "0.05")
+             "--prewarm-s", "0.05", "--no-live-pmc")
     assert d["metric"].startswith("1s@16kHz clips/sec") and d["unit"] == "clips/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and d["dtype"].startswith("bf16x3") and "workload" in d["config"]
@@ -51,3 +51,18 @@ def test_short_total_clips_stream_does_not_crash(monkeypatch, capsys):
     d = _run(monkeypatch, capsys, "--total-clips", "300", "--batch", "512", "--cpu-seconds", "0", "--prewarm-s", "0.05")
     assert d["scaling"] == "strong" and d["steps"] == 1 and d["value"] > 0
     assert d["roofline"]["clips_per_launch"] == 300 and "roofline_stft" not in d
+
+
+def test_roofline_traffic_is_collected_live_with_rocprofv3(monkeypatch, capsys):
+    """roofline.traffic of the default run comes from two `rocprofv3 --pmc` child runs of bench.py itself (FETCH_SIZE, WRITE_SIZE,
+    separate passes), not from a committed file: for the fused featurise + stem kernel at batch 512 it must sit at 1.34x the
+    SURVEY 8d bytes (the f32 a1 hand-off) within a few per cent."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    d = _run(monkeypatch, capsys, "--steps", "4", "--warmup", "1", "--batch", "512", "--cpu-seconds", "0", "--prewarm-s", "0.05")
+    r = d["roofline"]
+    assert r["traffic_source"].startswith("live: rocprofv3 --pmc"), r["traffic_source"]
+    assert 1.25 < r["traffic"] / (512 * 100360) < 1.45 and abs(r["traffic_over_algorithmic"] - r["traffic"] / (512 * 100360)) < 2e-3
+    rs = d["roofline_stft"]
+    assert rs["traffic_source"].startswith("live: rocprofv3 --pmc") and 0.97 < rs["traffic"] / (512 * 167828) < 1.08
