@@ -106,7 +106,7 @@ def live_pmc_traffic(args, kernels=("featurize_kernel", "stft3_kernel")):
             env.pop("WORLD_SIZE", None)
             try:
                 subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp",
-                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             except (subprocess.SubprocessError, OSError):
                 return None
             vals = {k: [] for k in kernels}
