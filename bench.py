@@ -21,9 +21,9 @@ Before ``--warmup`` an untimed pre-warm (``--prewarm-s``, default 0.6 s of the s
 the same as a long one.
 
 Extra objects on that line: ``roofline`` (featurise kernel vs HBM: algorithmic bytes per clip over the kernel's
-HIP-event time inside the timed region; ``traffic`` = HBM-side bytes per launch COLLECTED IN THIS RUN by two child runs of
-this script under ``rocprofv3 --pmc`` (FETCH_SIZE, WRITE_SIZE; ~4 s; ``--no-live-pmc`` or a missing rocprofv3 falls back to
-the committed record and says so in ``traffic_source``)), ``roofline_classifier`` (algorithmic 35.67 MFLOP/clip of the residual blocks
+HIP-event time inside the timed region; ``traffic`` = HBM-side bytes per launch COLLECTED IN THIS RUN by child runs of
+this script under ``rocprofv3 --pmc`` (FETCH_SIZE; WRITE_SIZE; MFMA busy -- three passes, ~6 s; ``--no-live-pmc`` or a missing
+rocprofv3 falls back to the committed record and says so in ``traffic_source``)), ``roofline_classifier`` (algorithmic 35.67 MFLOP/clip of the residual blocks
 vs the dense bf16 MFMA peak; the split-bf16 scheme issues 3 MFMAs per algorithmic one, reported as ``mfma_issue_frac``),
 ``roofline_stft`` (the STFT stage on its own) and ``cpu_baseline`` (the torch-CPU oracle timed on this box's host
 cores on a bounded sample; rank 0, N = 1 only).
@@ -82,13 +82,18 @@ def measured_pmc(batch: int, variant: str) -> dict:
     return {}
 
 
-def live_pmc_traffic(args, kernels=("featurize_kernel", "stft3_kernel")):
-    """HBM-side bytes per launch of the dominant kernel (and of the stand-alone STFT kernel), COLLECTED NOW: two child runs of this script under
-    ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE -- separate passes, counters only, no tracing; the program itself after
-    ``--``), corrected as MI355X_MICROARCH.md prescribes for gfx950 (both in KiB; FETCH_SIZE counts half the bytes of a
-    coalesced stream).  Children, never an exec: this process has initialised the GPU.  Returns
-    ``{kernel: {"traffic": bytes, "fetch": .., "write": .., "launches": n}}`` for the kernels that ran, or ``None`` (no
-    rocprofv3, a pass failed or timed out) -- the caller then falls back to the committed record."""
+LIVE_PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+LIVE_PMC_KERNELS = ("featurize_kernel", "stft3_kernel", "resblock_x3_kernel<32", "resblock_x3_kernel<64")
+
+
+def live_pmc(args, passes=LIVE_PMC_PASSES, kernels=LIVE_PMC_KERNELS):
+    """Hardware counters of this command's kernels, COLLECTED NOW: one child run of this script per pass under
+    ``rocprofv3 --pmc <counters>`` (separate passes, counters only, no tracing; the program itself after ``--``).  Children,
+    never an exec: this process has initialised the GPU.  Returns ``{kernel: {counter: mean per launch, "launches": n}}`` for
+    the kernels that ran, or ``None`` (no rocprofv3, a pass failed or timed out) -- the caller then falls back to the
+    committed records.  Derived figures (MI355X_MICROARCH.md): HBM-side bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 counts half
+    the bytes of a coalesced stream) + WRITE_SIZE[KiB] * 1024; MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8
+    XCDs * 1024 SIMDs)."""
     import csv
     import glob
     import shutil
@@ -97,36 +102,40 @@ def live_pmc_traffic(args, kernels=("featurize_kernel", "stft3_kernel")):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--prewarm-s", "0",
              "--batch", str(args.batch), "--dtype", args.dtype, "--no-live-pmc"] + (["--featurize-only"] if args.featurize_only else [])
-    got = {}
+    res = {}
     tmp = tempfile.mkdtemp(prefix="cough_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
+        for n, counters in enumerate(passes):
+            out = os.path.join(tmp, f"pass{n}")
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("WORLD_SIZE", None)
             try:
-                subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp",
+                subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp",
                                env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             except (subprocess.SubprocessError, OSError):
                 return None
-            vals = {k: [] for k in kernels}
+            sums = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") != counter:
+                        if r.get("Counter_Name") not in counters:
                             continue
                         for k in kernels:
                             if k in r.get("Kernel_Name", ""):
-                                vals[k].append(float(r["Counter_Value"]))
-            got[counter] = {k: (sum(v) / len(v), len(v)) for k, v in vals.items() if v}
+                                acc = sums.setdefault((k, r["Counter_Name"]), [0.0, 0])
+                                acc[0] += float(r["Counter_Value"])
+                                acc[1] += 1
+            for (k, c), (tot, cnt) in sums.items():
+                res.setdefault(k, {})[c] = tot / cnt
+                res[k]["launches"] = cnt
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    res = {}
-    for k in kernels:
-        if k in got.get("FETCH_SIZE", {}) and k in got.get("WRITE_SIZE", {}):
-            fetch_b, write_b = got["FETCH_SIZE"][k][0] * 1024 * 2, got["WRITE_SIZE"][k][0] * 1024
-            res[k] = {"traffic": int(fetch_b + write_b), "fetch": int(fetch_b), "write": int(write_b),
-                      "launches": got["FETCH_SIZE"][k][1]}
+    for k, d in res.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            d["fetch"], d["write"] = int(d["FETCH_SIZE"] * 1024 * 2), int(d["WRITE_SIZE"] * 1024)
+            d["traffic"] = d["fetch"] + d["write"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+            d["mfma_pipe_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
     return res or None
 
 
@@ -452,9 +461,9 @@ def main():
             traffic = int(traffic)
         if (world == 1 and not dist and not args.no_live_pmc and args.total_clips == 0 and Bk == B
                 and os.environ.get("COUGH_BENCH_LIVE_PMC", "1") == "1"):
-            live_all = live_pmc_traffic(args)
+            live_all = live_pmc(args)
             live = (live_all or {}).get("featurize_kernel")
-            if live is not None:
+            if live is not None and "traffic" in live:
                 traffic = live["traffic"]
                 traffic_src = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child runs of this command, {live['launches']} launches "
                                f"each): FETCH_SIZE[KiB]*1024*2 + WRITE_SIZE[KiB]*1024 = {live['fetch']} + {live['write']} bytes per launch")
@@ -507,11 +516,17 @@ def main():
                                            "frac": round(tf / peak, 4), "ms_per_forward": round(net_ms, 4),
                                            "mfma_per_product": MFMA_PER_PRODUCT[args.dtype],
                                            "mfma_issue_frac": round(MFMA_PER_PRODUCT[args.dtype] * tf / peak, 4)}
+            busy = {name: (live_all or {}).get(k, {}).get("mfma_pipe_busy")
+                    for name, k in (("block0", "resblock_x3_kernel<32"), ("block1", "resblock_x3_kernel<64"))}
+            if all(v is not None for v in busy.values()):
+                # PMC, collected in this run: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) per kernel
+                line["roofline_classifier"]["mfma_pipe_busy"] = busy
+                line["roofline_classifier"]["mfma_pipe_busy_source"] = "live: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (child run of this command)"
         stft_in = [b_ for b_ in batches[:8] if b_.shape[0] == B]
         if world == 1 and not dist and stft_in:
             line["roofline_stft"] = stft_stage(pre, stft_in)
             lv = (live_all or {}).get("stft3_kernel")
-            if lv is not None:     # the child runs launched the stand-alone STFT kernel too: its traffic from the same passes
+            if lv is not None and "traffic" in lv:     # the child runs launched the stand-alone STFT kernel too
                 rs = line["roofline_stft"]
                 rs["traffic"] = lv["traffic"]
                 rs["traffic_source"] = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ({lv['launches']} launches): "

@@ -66,3 +66,5 @@ def test_roofline_traffic_is_collected_live_with_rocprofv3(monkeypatch, capsys):
     assert 1.25 < r["traffic"] / (512 * 100360) < 1.45 and abs(r["traffic_over_algorithmic"] - r["traffic"] / (512 * 100360)) < 2e-3
     rs = d["roofline_stft"]
     assert rs["traffic_source"].startswith("live: rocprofv3 --pmc") and 0.97 < rs["traffic"] / (512 * 167828) < 1.08
+    busy = d["roofline_classifier"]["mfma_pipe_busy"]
+    assert 0.05 < busy["block0"] < 1.0 and 0.05 < busy["block1"] < 1.0
