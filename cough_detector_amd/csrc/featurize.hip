@@ -590,9 +590,9 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                       "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
         for (int i = 0; i <= cfg->n_contrast_bands; ++i) {
             const int lo = cfg->contrast_edges[i], hi = cfg->contrast_edges[i + 1];
-            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= 128), COUGH_EUNSUPPORTED,
-                          "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= 128 bins inside "
-                          "the spectrum", i, lo, hi);
+            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= (tuned ? 128 : 1024)),
+                          COUGH_EUNSUPPORTED, "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= %d bins "
+                          "inside the spectrum", i, lo, hi, tuned ? 128 : 1024);
         }
     }
     std::vector<FeatTables> host(1);

@@ -37,7 +37,7 @@ constexpr int G_XROW = 17, G_XFRAME = 16 * G_XROW;
 constexpr int G_FPB = 16;        // frames per gen_stft workgroup: 4 waves x 4 frames
 constexpr int G_TT = 64;         // frames per workgroup of the per-frame kernels (lane = frame)
 constexpr int G_MAX_MELS = 128;
-constexpr int G_CT_BINS = 128;   // widest spectral-contrast band (bins)
+constexpr int G_CT_BINS = 128;   // spectral-contrast bands up to this many bins fill the 32 KB tile with 64 frames (wider: fewer frames)
 constexpr size_t G_SUB_BYTES = size_t(192) << 20;   // intermediates of one sub-batch: inside the 256 MiB Infinity Cache
 
 __device__ __forceinline__ float g_block_max(float v, float* red, int tid) {
@@ -376,26 +376,35 @@ __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restric
         if (high <= low) high = low + 1;
         if (high > nfreq) high = nfreq;
         const int nb = high - low;
-        __syncthreads();
-        for (int e = 0; e < nb; ++e) band[e * G_TT + lane] = t < T ? Pc[(long long)(low + e) * T + t] : 0.f;
-        __syncthreads();
         int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
         if (top_idx < 1) top_idx = 1;
         if (bot_idx < 1) bot_idx = 1;
-        float top = 0.f, bot = 0.f;
-        for (int e = 0; e < nb; ++e) {
-            const float v = band[e * G_TT + lane];
-            int rank = 0;
-            for (int q = 0; q < nb; ++q) {
-                const float u = band[q * G_TT + lane];
-                rank += (u < v || (u == v && q < e)) ? 1 : 0;
+        // the band's rows of FT frames at a time in the 32 KB tile: 64 frames for bands of <= 128 bins (every band of
+        // n_fft <= 1024), 32 / 16 / 8 frames for the wider bands of n_fft = 2048
+        const int FT = nb <= G_CT_BINS ? G_TT : nb <= 2 * G_CT_BINS ? G_TT / 2 : nb <= 4 * G_CT_BINS ? G_TT / 4 : G_TT / 8;
+        for (int sub = 0; sub < G_TT / FT; ++sub) {
+            const int ts = blockIdx.x * G_TT + sub * FT + lane;
+            __syncthreads();
+            if (lane < FT)
+                for (int e = 0; e < nb; ++e) band[e * FT + lane] = ts < T ? Pc[(long long)(low + e) * T + ts] : 0.f;
+            __syncthreads();
+            if (lane < FT) {
+                float top = 0.f, bot = 0.f;
+                for (int e = 0; e < nb; ++e) {
+                    const float v = band[e * FT + lane];
+                    int rank = 0;
+                    for (int q = 0; q < nb; ++q) {
+                        const float u = band[q * FT + lane];
+                        rank += (u < v || (u == v && q < e)) ? 1 : 0;
+                    }
+                    if (rank >= top_idx) top += v;
+                    if (rank < bot_idx) bot += v;
+                }
+                const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
+                const float valleys = bot / float(bot_idx);
+                if (ts < T) o[(long long)i * T + ts] = log1pf(peaks) - log1pf(valleys);
             }
-            if (rank >= top_idx) top += v;
-            if (rank < bot_idx) bot += v;
         }
-        const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
-        const float valleys = bot / float(bot_idx);
-        if (t < T) o[(long long)i * T + t] = log1pf(peaks) - log1pf(valleys);
     }
     if (t < T) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
         float num = 0.f, den = 0.f;

@@ -112,3 +112,47 @@ def test_stream_detector_reset_and_chunk_length_change():
         out.append(log)
     assert out[0] == out[1]
     assert all(len(p) == 7 for p in out[0][0])          # (40000 - 16000) / 4000 + 1 windows per stream
+
+
+def test_featuriser_random_geometries_and_flags():
+    """40 seeded random AudioPreprocessor constructor calls -- sample_rate, n_fft (powers of two), hop, win (odd / even / tiny),
+    n_mels (more bands than bins included: empty bands), n_mfcc, f_min / f_max (up to Nyquist), window length, every flag --
+    against the CPU oracle with the same arguments; the wide spectral-contrast bands of n_fft = 2048 included."""
+    from test_oracle_featurizer import geometry_clip
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        sr = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100]))
+        n_fft = int(rng.choice([128, 256, 512, 512, 1024, 2048]))
+        win = int(rng.integers(max(8, n_fft // 8), n_fft + 1))
+        hop = int(rng.integers(max(4, n_fft // 16), n_fft + 40))
+        n_mels = int(rng.choice([13, 32, 40, 64, 80, 96, 128]))
+        n_mfcc = int(rng.integers(1, min(n_mels, 40) + 1))
+        f_min = float(rng.choice([0.0, 20.0, 100.0, 300.0]))
+        f_max = float(min(sr / 2, rng.choice([3000.0, 4000.0, 8000.0, 16000.0])))
+        if f_max <= f_min + 500:
+            f_max = sr / 2
+        n = int(rng.integers(n_fft // 2 + 1, 3 * sr // 2))
+        flags = dict(use_pre_emphasis=bool(rng.integers(2)), use_delta_delta=bool(rng.integers(2)), use_pcen=bool(rng.integers(2)),
+                     use_mfcc=bool(rng.integers(4) > 0), use_spectral_contrast=bool(rng.integers(3) == 0),
+                     n_contrast_bands=int(rng.integers(1, 5)))
+        g = dict(sample_rate=sr, n_mels=n_mels, n_fft=n_fft, hop_length=hop, win_length=win, f_min=f_min, f_max=f_max, n_mfcc=n_mfcc)
+        pre = cda.AudioPreprocessor(device="cuda", segment_duration=n / sr, **g, **flags)
+        n = pre.segment_samples
+        w = torch.from_numpy(np.stack([geometry_clip(case + s, n) for s in (0, 3)]))
+        f = pre.featurize_batch(w.cuda(), normalize=True).cpu()          # no combination in these ranges is refused
+        ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g), **flags)
+        assert f.shape == ref.shape, (case, g, flags, f.shape, ref.shape)
+        nbase = n_mels + ((2 * n_mfcc + (n_mfcc if flags["use_delta_delta"] else 0)) if flags["use_mfcc"] else 0)
+        mel = (f[:, :n_mels] - ref[:, :n_mels]).abs().max().item()
+        zr = f[:, n_mels:nbase], ref[:, n_mels:nbase]
+        rel = ((zr[0] - zr[1]).abs() / zr[1].abs().clamp(min=1.0)).max().item() if nbase > n_mels else 0.0
+        cerr, nan_rule = 0.0, True
+        if flags["use_spectral_contrast"]:
+            fc, rc = f[:, nbase:], ref[:, nbase:]
+            nan_rule = bool(torch.equal(torch.isnan(fc), torch.isnan(rc)))      # a one-bin first band: NaN rows in both (:272-300)
+            both = ~torch.isnan(rc) & ~torch.isnan(fc)
+            cerr = (fc[both] - rc[both]).abs().max().item() if both.any() else 0.0
+        ok = mel < FEAT_TOL and rel < 3 * FEAT_TOL and cerr < 3 * FEAT_TOL and nan_rule and bool(torch.isfinite(f[:, :nbase]).all())
+        print(f"case {case:2d}: sr {sr} n_fft {n_fft} win {win} hop {hop} mels {n_mels} mfcc {n_mfcc} f {f_min:.0f}-{f_max:.0f} N {n} "
+              f"{[k[4:] for k, v in flags.items() if v is True]}: mel {mel:.1e} z {rel:.1e} contrast {cerr:.1e}{'' if ok else '   <-- FAIL'}")
+        assert ok, (case, g, flags, mel, rel, cerr)
