@@ -156,3 +156,31 @@ def test_featuriser_random_geometries_and_flags():
         print(f"case {case:2d}: sr {sr} n_fft {n_fft} win {win} hop {hop} mels {n_mels} mfcc {n_mfcc} f {f_min:.0f}-{f_max:.0f} N {n} "
               f"{[k[4:] for k, v in flags.items() if v is True]}: mel {mel:.1e} z {rel:.1e} contrast {cerr:.1e}{'' if ok else '   <-- FAIL'}")
         assert ok, (case, g, flags, mel, rel, cerr)
+
+
+def test_realtime_preprocessor_random_chunk_lengths_and_hops():
+    """RealtimePreprocessor.add_audio (src/preprocessing.py:582-616) with random chunk lengths (1 sample .. 1.7 windows: several
+    windows per call, calls that complete none), hop durations and window lengths: the same windows in the same calls as the
+    restated FIFO, features within tolerance; (1, n) and (n,) chunks; reset()."""
+    rng = np.random.default_rng(99)
+    for win_s, hop_s in ((1.0, 0.25), (1.0, 0.5), (0.5, 0.1), (2.0, 0.33)):
+        rt = cda.RealtimePreprocessor(window_duration=win_s, hop_duration=hop_s, device="cuda", **SHIPPED)
+        ow = ofeat.RealtimeWindowerOracle(win_s, hop_s)
+        stream = torch.from_numpy(synth.make_stream(int(win_s * 10 + hop_s * 100), 4.0 * win_s + 1.0))
+        pos, n_win, calls_with_many = 0, 0, 0
+        while pos < stream.numel():
+            n = int(rng.choice([1, 7, 160, 1600, 4000, int(16000 * win_s * 1.7)]))
+            chunk = stream[pos:pos + n]
+            pos += n
+            if rng.integers(2):
+                chunk = chunk.unsqueeze(0)                                   # (1, n) as well as (n,)
+            got, want = rt.add_audio(chunk), ow.add_audio(chunk)
+            assert len(got) == len(want), (win_s, hop_s, pos, len(got), len(want))
+            calls_with_many += len(got) > 1
+            for g, r in zip(got, want):
+                mel, rel = feature_errors(g, r)
+                assert g.shape == r.shape and mel < FEAT_TOL and rel < FEAT_TOL
+                n_win += 1
+        assert n_win >= 8 and calls_with_many >= 1 and rt.buffer.shape == ow.buffer.shape
+        rt.reset()
+        assert rt.buffer.shape == (1, 0) and rt.add_audio(stream[:100]) == []
