@@ -113,6 +113,7 @@ class AudioPreprocessor:
         self._dct = _tables.dct_matrix(n_mfcc, n_mels)
         self._handle: Optional[C.c_void_p] = None
         self._length_handles = {}                   # other waveform lengths -> featuriser handles (extract_features of any N)
+        self._retired = []                          # handles evicted from that cache (freed in __del__)
         self._ws: Optional[torch.Tensor] = None     # scratch of the spectral-contrast rows / the generic kernel chain
         self._resamplers = {}
 
@@ -129,9 +130,11 @@ class AudioPreprocessor:
                 if n_samples <= self.n_fft // 2:
                     raise ValueError(f"a waveform of {n_samples} samples is shorter than the reflect padding of "
                                      f"torch.stft(center=True) (needs more than n_fft // 2 = {self.n_fft // 2})")
-                if len(self._length_handles) >= self.MAX_LENGTH_HANDLES:          # drop the oldest length
+                if len(self._length_handles) >= self.MAX_LENGTH_HANDLES:          # retire the oldest length
+                    # not destroyed here: another thread / a launch in flight may still use its tables (a handle is ~20 KB of
+                    # device memory); retired handles are freed with the preprocessor
                     old = next(iter(self._length_handles))
-                    _lib.load().cough_featurizer_destroy(self._length_handles.pop(old))
+                    self._retired.append(self._length_handles.pop(old))
                 h = self._length_handles[n_samples] = self._create_handle(n_samples)
             return h
         if self._handle is None:
@@ -157,8 +160,9 @@ class AudioPreprocessor:
         return h
 
     def __del__(self):
-        handles = [getattr(self, "_handle", None)] + list(getattr(self, "_length_handles", {}).values())
-        self._handle, self._length_handles = None, {}
+        handles = [getattr(self, "_handle", None)] + list(getattr(self, "_length_handles", {}).values()) + \
+            list(getattr(self, "_retired", []))
+        self._handle, self._length_handles, self._retired = None, {}, []
         for h in handles:
             if h is not None:
                 try:
