@@ -247,6 +247,71 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ STFT, ANY n_fft (direct DFT)
+// An n_fft that is not a power of two (torchaudio's own default is 400): X[k] = sum_n x[n] w[n] e^{-2 pi i k n / n_fft} evaluated
+// directly -- one wave per frame, the windowed frame and the n_fft twiddles (computed in double on the host) in LDS, lane =
+// bin, the twiddle index (k n) mod n_fft stepped incrementally, four interleaved partial sums per bin (shorter error chains).
+// O(n_fft^2) per frame: a generality fallback (16 M FMA per 1 s clip at n_fft = 400), not a throughput path.
+template <bool MAG, bool MEL>
+__global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
+                                                           int nfft, const float* __restrict__ win /* [nfft] */,
+                                                           const float2* __restrict__ twf /* [nfft]: e^{-2 pi i j / nfft} */,
+                                                           const float* __restrict__ peaks, int pre_emph, float coef,
+                                                           float* __restrict__ out, GenMel mel) {
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    const int nfreq = nfft / 2 + 1, pad = nfft / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* tw = reinterpret_cast<float2*>(smem_d);                                   // [nfft]
+    float* xw = reinterpret_cast<float*>(tw + nfft) + size_t(wave) * nfft;            // [4][nfft] windowed frames
+    float* spec = reinterpret_cast<float*>(tw + nfft) + size_t(4) * nfft + size_t(wave) * (nfreq + 1);
+    for (int j = tid; j < nfft; j += 256) tw[j] = twf[j];
+    const long long clip = blockIdx.y;
+    const int t_raw = blockIdx.x * 4 + wave, t = t_raw < T ? t_raw : T - 1;
+    const float* x = wav + clip * stride;
+    const float m = peaks ? peaks[clip] : 0.f;
+    const float inv_m = m > 0.f ? 1.0f / m : 1.0f;
+    auto sample = [&](int i) -> float { return x[i] * inv_m; };
+    auto value = [&](int i) -> float {
+        i = i < 0 ? -i : (i >= N ? 2 * (N - 1) - i : i);
+        float v = sample(i);
+        if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));
+        return v;
+    };
+    const int s0 = hop * t - pad;
+    for (int n = lane; n < nfft; n += 64) xw[n] = value(s0 + n) * win[n];
+    __syncthreads();
+    for (int k = lane; k < nfreq; k += 64) {
+        float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
+        int idx = 0;                                   // (k n) mod nfft
+        for (int n = 0; n < nfft; ++n) {
+            const float2 w = tw[idx];
+            const float v = xw[n];
+            re[n & 3] = fmaf(v, w.x, re[n & 3]);
+            im[n & 3] = fmaf(v, w.y, im[n & 3]);
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        const float xr = (re[0] + re[1]) + (re[2] + re[3]), xi = (im[0] + im[1]) + (im[2] + im[3]);
+        const float pw = xr * xr + xi * xi;
+        spec[k] = MAG ? sqrtf(pw) : pw;
+    }
+    wave_lds_fence();
+    if (t_raw >= T) return;
+    if constexpr (MEL) {
+        float* o = out + clip * (long long)mel.n_mels * T;
+        for (int mb = lane; mb < mel.n_mels; mb += 64) {
+            const int l = mel.lo[mb], hb = mel.hi[mb];
+            const float* wm = mel.w + mel.off[mb];
+            float acc = 0.f;
+            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], spec[k], acc);
+            o[(long long)mb * T + t] = acc;
+        }
+    } else {
+        float* o = out + clip * (long long)nfreq * T;
+        for (int k = lane; k < nfreq; k += 64) o[(long long)k * T + t] = spec[k];
+    }
+}
+
 // AmplitudeToDB('power'): 10 log10(max(x, amin = 1e-10)) (ref = 1: no offset)
 __device__ __forceinline__ float g_db(float p) { return 10.0f * log10f(fmaxf(p, 1e-10f)); }
 // PCEN value of apply_pcen (:305-340): smooth = 10-frame moving average (avg_pool2d kernel 10, padding 5, zeros counted,
@@ -457,13 +522,14 @@ size_t pow2_lds_bytes(int nfft) { return size_t(4) * 2 * (nfft / 2) * 8 + size_t
 
 struct GenFeat {
     int N, hop, T, n_mels, n_mfcc, sample_rate;
-    int nfft, nfreq;       // n_fft (a power of two, 64 .. 2048) and n_fft / 2 + 1
+    int nfft, nfreq;       // n_fft (16 .. 2048) and n_fft / 2 + 1
     char* d_blob;
     const float* win;      // [n_fft] caller's window centred in the frame
     const float* win_full; // [n_fft] periodic Hann(n_fft)
     const float2* tw256;   // [16][16]            (the 512-point kernels)
     const float2* tw512;   // [128]
     const float2* twn;     // [n_fft / 2 + 1] W_n_fft^k (gen_stft_pow2_kernel)
+    const float2* twf;     // [n_fft] W_n_fft^j, all of them (gen_stft_dft_kernel: n_fft not a power of two)
     const int *mel_lo, *mel_hi, *mel_off;
     const float* mel_w;    // CSR taps
     const float* dct_t;    // [n_mfcc][n_mels]
@@ -471,24 +537,30 @@ struct GenFeat {
 };
 
 namespace {
-// one STFT launch of the chain: the register radix-16 x radix-16 kernel at n_fft = 512, the Stockham kernel otherwise
+// one STFT launch of the chain: the register radix-16 x radix-16 kernel at n_fft = 512, the Stockham kernel for the other
+// powers of two, the direct DFT for everything else
 template <bool MAG, bool MEL>
 void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int nc, const float* win, const float* peaks,
                      int pre_emph, float coef, float* out, const GenMel& mel, hipStream_t stream) {
     if (g->nfft == G_NFFT) {
         hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((g->T + G_FPB - 1) / G_FPB, nc), dim3(256), 0, stream, w, wav_stride,
                            g->N, g->hop, g->T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel);
-    } else {
+    } else if (g->nfft >= 64 && (g->nfft & (g->nfft - 1)) == 0) {
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
+    } else {
+        const size_t lds = size_t(g->nfft) * 8 + size_t(4) * g->nfft * 4 + size_t(4) * (g->nfft / 2 + 2) * 4;   // <= 58 KB
+        hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), lds, stream, w, wav_stride, g->N,
+                           g->hop, g->T, g->nfft, win, g->twf, peaks, pre_emph, coef, out, mel);
     }
 }
 }  // namespace
 
 int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* window, const float* mel_fb, const float* dct) {
     const int nfft = cfg->n_fft, nfreq = nfft / 2 + 1;
-    COUGH_REQUIRE(nfft >= 64 && nfft <= 2048 && (nfft & (nfft - 1)) == 0, COUGH_EUNSUPPORTED,
-                  "n_fft = %d: the HIP path implements the powers of two 64 .. 2048 (512 on the register FFT kernels)", nfft);
+    COUGH_REQUIRE(nfft >= 16 && nfft <= 2048, COUGH_EUNSUPPORTED,
+                  "n_fft = %d: the HIP path implements 16 .. 2048 (512 on the register FFT kernels, the other powers of two "
+                  "from 64 on a radix-2 kernel, anything else by direct DFT)", nfft);
     COUGH_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= nfft, COUGH_EUNSUPPORTED,
                   "win_length = %d: need 1 <= win_length <= n_fft", cfg->win_length);
     COUGH_REQUIRE(cfg->hop_length >= 1, COUGH_EINVAL, "hop_length = %d", cfg->hop_length);
@@ -503,14 +575,15 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     const int n_mels = cfg->n_mels, n_mfcc = cfg->use_mfcc ? cfg->n_mfcc : 0;   // T.MFCC exists only with use_mfcc (:116-127)
     const double PI = 3.14159265358979323846;
     std::vector<float> win(nfft, 0.f), hann(nfft), freqs(nfreq), dct_t(size_t(n_mfcc) * n_mels), taps;
-    std::vector<float2> tw256(256), tw512(128), twn(nfreq);
+    std::vector<float2> tw256(256), tw512(128), twn(nfreq), twf(nfft);
     std::vector<int> lo(n_mels), hi(n_mels), off(n_mels);
     const int left = (nfft - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
     for (int n = 0; n < cfg->win_length; ++n) win[left + n] = window[n];
     for (int n = 0; n < nfft; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(nfft)));
-    for (int k = 0; k < nfreq; ++k) {
+    for (int k = 0; k < nfft; ++k) {
         const double a = -2.0 * PI * double(k) / double(nfft);
-        twn[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        twf[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+        if (k < nfreq) twn[k] = twf[k];
     }
     for (int jj = 0; jj < 16; ++jj)
         for (int k1 = 0; k1 < 16; ++k1) {
@@ -545,7 +618,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     }
     // one device blob
     size_t o_win = 0, o_hann = o_win + align256g(nfft * 4), o_tw256 = o_hann + align256g(nfft * 4),
-           o_tw512 = o_tw256 + align256g(256 * 8), o_twn = o_tw512 + align256g(128 * 8), o_lo = o_twn + align256g(nfreq * 8),
+           o_tw512 = o_tw256 + align256g(256 * 8), o_twn = o_tw512 + align256g(128 * 8), o_twf = o_twn + align256g(nfreq * 8), o_lo = o_twf + align256g(nfft * 8),
            o_hi = o_lo + align256g(n_mels * 4),
            o_off = o_hi + align256g(n_mels * 4), o_taps = o_off + align256g(n_mels * 4),
            o_dct = o_taps + align256g(taps.size() * 4), o_freqs = o_dct + align256g(dct_t.size() * 4),
@@ -556,6 +629,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     std::memcpy(host.data() + o_tw256, tw256.data(), 256 * 8);
     std::memcpy(host.data() + o_tw512, tw512.data(), 128 * 8);
     std::memcpy(host.data() + o_twn, twn.data(), nfreq * 8);
+    std::memcpy(host.data() + o_twf, twf.data(), nfft * 8);
     std::memcpy(host.data() + o_lo, lo.data(), n_mels * 4);
     std::memcpy(host.data() + o_hi, hi.data(), n_mels * 4);
     std::memcpy(host.data() + o_off, off.data(), n_mels * 4);
@@ -565,7 +639,9 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     GenFeat* g = new GenFeat();
     g->N = cfg->segment_samples;
     g->hop = cfg->hop_length;
-    g->T = cfg->segment_samples / cfg->hop_length + 1;   // get_expected_time_frames(), :532-534
+    // frames of torch.stft(center=True): 1 + (N + 2 (n_fft / 2) - n_fft) / hop = N / hop + 1 (get_expected_time_frames(),
+    // :532-534) for an even n_fft, one sample less of signal for an odd one
+    g->T = (cfg->segment_samples - (nfft & 1)) / cfg->hop_length + 1;
     g->n_mels = n_mels;
     g->n_mfcc = n_mfcc;
     g->sample_rate = cfg->sample_rate;
@@ -586,6 +662,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     g->tw256 = reinterpret_cast<const float2*>(b + o_tw256);
     g->tw512 = reinterpret_cast<const float2*>(b + o_tw512);
     g->twn = reinterpret_cast<const float2*>(b + o_twn);
+    g->twf = reinterpret_cast<const float2*>(b + o_twf);
     g->mel_lo = reinterpret_cast<const int*>(b + o_lo);
     g->mel_hi = reinterpret_cast<const int*>(b + o_hi);
     g->mel_off = reinterpret_cast<const int*>(b + o_off);
@@ -595,7 +672,10 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     if (nfft != G_NFFT) {   // gen_stft_pow2_kernel: 4 waves x (two ping-pong buffers + a spectrum) of dynamic LDS, > 64 KB at 2048
         const void* fns[] = {reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, false>),
                              reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, true>),
-                             reinterpret_cast<const void*>(gen_stft_pow2_kernel<true, false>)};
+                             reinterpret_cast<const void*>(gen_stft_pow2_kernel<true, false>),
+                             reinterpret_cast<const void*>(gen_stft_dft_kernel<false, false>),
+                             reinterpret_cast<const void*>(gen_stft_dft_kernel<false, true>),
+                             reinterpret_cast<const void*>(gen_stft_dft_kernel<true, false>)};
         for (const void* fn : fns)
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(pow2_lds_bytes(2048))) != hipSuccess) {
                 set_error("cough_featurizer_create (generic geometry): hipFuncSetAttribute failed");

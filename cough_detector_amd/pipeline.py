@@ -36,12 +36,12 @@ class CoughPipeline:
         logits = torch.empty((b, 2), dtype=torch.float32, device=dev)
         probs = torch.empty((b, 2), dtype=torch.float32, device=dev) if want_probs else None
         preds = torch.empty((b,), dtype=torch.int32, device=dev) if want_probs else None
-        feats = (torch.empty((b, self.pre.get_num_features(), self.pre.get_expected_time_frames()),
+        feats = (torch.empty((b, self.pre.get_num_features(), self.pre._frames(self.pre.segment_samples)),
                              dtype=torch.float32, device=dev) if return_features else None)
         if b and not isinstance(self.model, CoughDetectorResidual):
             # conv-stack classifiers (CoughDetector / CoughDetectorSmall): featurise, then cough_cnn_forward
             if feats is None:
-                feats = torch.empty((b, self.pre.get_num_features(), self.pre.get_expected_time_frames()),
+                feats = torch.empty((b, self.pre.get_num_features(), self.pre._frames(self.pre.segment_samples)),
                                     dtype=torch.float32, device=dev)
             if events:
                 events[0].record()

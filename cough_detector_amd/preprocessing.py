@@ -13,10 +13,10 @@ Differences a caller can observe:
   ``(B, F, T)`` with the reference's per-clip reduction semantics; like the reference it takes a waveform of ANY
   length N (T = 1 + N // hop_length): ``segment_samples`` runs on the tuned kernel, other lengths on the generic chain.
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
-  spectral contrast + centroid) for every geometry with a power-of-two ``n_fft`` (64..2048): any ``sample_rate`` /
+  spectral contrast + centroid) for every geometry with ``n_fft`` in 16..2048: any ``sample_rate`` /
   ``hop_length`` / ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The
   shipped geometry runs on the tuned one-launch kernel, the others on a chain of small kernels
-  (``csrc/featurize_generic.hip``); another ``n_fft`` raises ``ValueError``.
+  (``csrc/featurize_generic.hip``); ``n_fft`` > 2048 raises ``ValueError``.
 * ``use_spectral_contrast=True`` with 5 or more bands (the constructor default is 6) yields NaN rows exactly as
   the reference does (its first band is one bin wide, ``src/preprocessing.py:272-290``); a warning says so.
 """
@@ -91,11 +91,12 @@ class AudioPreprocessor:
                           "bin wide); this implementation reproduces them. Use use_spectral_contrast=False (the "
                           "shipped configuration, src/train.py:264-287) or n_contrast_bands <= 4.", stacklevel=2)
         # Geometry: the tuned one-kernel path serves the shipped 16 kHz / 512 / 160 / 400 / 64 mel / 13 MFCC / 1 s layout with
-        # f_max <= sample_rate / 4; every other geometry (n_fft a power of two) runs on the generic kernel chain
+        # f_max <= sample_rate / 4; every other geometry (any n_fft in 16..2048) runs on the generic kernel chain
         # (csrc/featurize_generic.hip) -- the library picks.  What torch / torchaudio would refuse is refused here too.
-        if not (64 <= n_fft <= 2048 and n_fft & (n_fft - 1) == 0):
-            raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements the powers of two 64..2048 "
-                             "(512, the reference's default, on the register FFT kernels)")
+        if not 16 <= n_fft <= 2048:
+            raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements n_fft = 16..2048 (512, the "
+                             "reference's default, on the register FFT kernels; other powers of two on a radix-2 kernel; "
+                             "anything else by direct DFT)")
         if not 1 <= win_length <= n_fft:
             raise ValueError(f"AudioPreprocessor: win_length={win_length} must lie in 1..n_fft (torch.stft)")
         if hop_length < 1:
@@ -278,6 +279,11 @@ class AudioPreprocessor:
     def get_expected_time_frames(self) -> int:
         return (self.segment_samples // self.hop_length) + 1
 
+    def _frames(self, n_samples: int) -> int:
+        """Frames torch.stft(center=True) yields for n_samples: n // hop + 1 for an even n_fft (= get_expected_time_frames()
+        for the segment), computed from one sample less for an odd n_fft (the padded length is then n + n_fft - 1)."""
+        return (n_samples - (self.n_fft & 1)) // self.hop_length + 1
+
     def get_num_features(self) -> int:
         n = self.n_mels
         if self.use_mfcc:
@@ -305,7 +311,7 @@ class AudioPreprocessor:
         if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
             w = w.contiguous()
         b = w.shape[0]
-        f, t = self.get_num_features(), n_samples // self.hop_length + 1
+        f, t = self.get_num_features(), self._frames(n_samples)
         if out is None:
             out = torch.empty((b, f, t), dtype=torch.float32, device=dev)
         elif tuple(out.shape) != (b, f, t) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
@@ -342,7 +348,7 @@ class AudioPreprocessor:
         w = waveforms.to(device=dev, dtype=torch.float32)
         if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
             w = w.contiguous()
-        b, shape = w.shape[0], (w.shape[0], self.n_fft // 2 + 1, n_samples // self.hop_length + 1)
+        b, shape = w.shape[0], (w.shape[0], self.n_fft // 2 + 1, self._frames(n_samples))
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=dev)
         elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:

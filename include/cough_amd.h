@@ -44,16 +44,18 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
 /* ------------------------------------------------------------------ featuriser (K1)
  * Replaces AudioPreprocessor.__init__ / extract_features / normalize
  * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for every flag of the
- * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry with a
- * power-of-two n_fft (64 .. 2048): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 128,
+ * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry with
+ * 16 <= n_fft <= 2048 (even or odd): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 128,
  * n_mfcc <= n_mels, any filterbank (f_min / f_max), any segment longer than n_fft / 2 samples (RealtimePreprocessor's
  * window_duration, :559-580; the engine's re-construction from a checkpoint config,
  * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry,
  * which (with a filterbank of <= 8 taps per band below bin 128, i.e. f_max <= sample_rate / 4) runs on
  * the tuned one-launch kernel; every other geometry runs on a chain of small kernels and NEEDS A
  * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft = 512 (the reference's
- * default) uses the register radix-16 x radix-16 FFT, the other powers of two a radix-2 Stockham kernel; an n_fft
- * that is not a power of two returns COUGH_EUNSUPPORTED.  Output row order as the reference concatenates (:456-487): mel[0:n_mels]
+ * default) uses the register radix-16 x radix-16 FFT, the other powers of two >= 64 a radix-2 Stockham kernel, every
+ * other n_fft (400 = torchaudio's own default, odd sizes) a direct DFT -- exact, O(n_fft^2), about 10x slower; the frame
+ * count is torch.stft's, (N - n_fft % 2) / hop_length + 1; n_fft outside 16 .. 2048 returns COUGH_EUNSUPPORTED.
+ * Output row order as the reference concatenates (:456-487): mel[0:n_mels]
  * (log-mel or PCEN), MFCC, delta, (delta-delta), (spectral contrast + centroid). */
 #define COUGH_MAX_CONTRAST_BANDS 16
 typedef struct cough_feat_config {

@@ -26,7 +26,7 @@ def frames(x: np.ndarray, hop: int = HOP, n_fft: int = N_FFT) -> np.ndarray:
     x = np.asarray(x, dtype=np.float64)
     pad = n_fft // 2
     xp = np.concatenate([x[1:pad + 1][::-1], x, x[-pad - 1:-1][::-1]])
-    t = 1 + len(x) // hop
+    t = 1 + (len(xp) - n_fft) // hop                         # = 1 + N // hop for an even n_fft
     idx = np.arange(n_fft)[None, :] + hop * np.arange(t)[:, None]
     return xp[idx]
 

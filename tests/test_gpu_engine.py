@@ -51,7 +51,7 @@ def test_engine_matches_oracle_stream(tmp_path):
 def test_engine_rejects_unsupported_checkpoints(tmp_path):
     sd = synth.random_state_dict(seed=5)
     path = str(tmp_path / "m.pt")
-    torch.save({"model_state_dict": sd, "config": {**CONFIG, "n_fft": 400}}, path)
+    torch.save({"model_state_dict": sd, "config": {**CONFIG, "n_fft": 4096}}, path)
     with pytest.raises(ValueError, match="n_fft"):
         cda.CoughDetectorInference(path, verbose=False)
     torch.save({"model_state_dict": sd, "config": {**CONFIG, "model_type": "small"}}, path)

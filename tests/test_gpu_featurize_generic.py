@@ -41,8 +41,9 @@ def test_geometry_against_oracle(name):
     w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(10)]))
     w[7] = 0.0                                                              # digital silence: amin clamp, no NaN
     f = pre.extract_features(w.cuda())
-    nm, T = g["n_mels"], 1 + n // g["hop_length"]
-    assert f.shape == (10, nm + 2 * g["n_mfcc"], T) == (10, pre.get_num_features(), pre.get_expected_time_frames())
+    nm, T = g["n_mels"], 1 + (n - g.get("n_fft", 512) % 2) // g["hop_length"]
+    assert f.shape == (10, nm + 2 * g["n_mfcc"], T) == (10, pre.get_num_features(), pre._frames(n))
+    assert pre.get_expected_time_frames() == 1 + n // g["hop_length"]      # the reference's helper (:532-534), n_fft-blind
     ref = ofeat.extract_features_batch(w, **ofeat.geometry_kwargs(**g))
     mel, rel = errors(f, ref, nm)
     print(f"{name}: {tuple(f.shape)} mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
@@ -138,7 +139,7 @@ def test_realtime_two_second_windows_through_the_engine(tmp_path):
 
 def test_geometry_errors_match_what_torch_would_refuse():
     with pytest.raises(ValueError, match="n_fft"):
-        cda.AudioPreprocessor(n_fft=400, **SHIPPED)
+        cda.AudioPreprocessor(n_fft=4096, **SHIPPED)
     with pytest.raises(ValueError, match="win_length"):
         cda.AudioPreprocessor(win_length=600, **SHIPPED)
     with pytest.raises(ValueError, match="MFCC coefficients"):
@@ -215,12 +216,15 @@ def test_extract_features_takes_a_waveform_of_any_length_like_the_reference():
         pre.extract_features(torch.zeros(1, 200))
 
 
-@pytest.mark.parametrize("n_fft,flags", [(1024, dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)),
+@pytest.mark.parametrize("n_fft,flags", [(400, dict(use_pre_emphasis=True, use_spectral_contrast=True, n_contrast_bands=3)),
+                                         (301, dict(use_delta_delta=True, use_pcen=True)), (1000, dict()), (32, dict(use_mfcc=False)),
+                                         (1024, dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)),
                                          (1024, dict(use_spectral_contrast=True, n_contrast_bands=4)),
                                          (256, dict(use_spectral_contrast=True, n_contrast_bands=3, use_pre_emphasis=True)),
                                          (64, dict(use_mfcc=False)), (2048, dict(use_delta_delta=True))])
-def test_other_power_of_two_n_fft_with_flags(n_fft, flags):
-    """n_fft other than 512 (radix-2 Stockham kernel): every flag, the stand-alone STFT stage included."""
+def test_other_n_fft_with_flags(n_fft, flags):
+    """n_fft other than 512 -- powers of two on the radix-2 Stockham kernel, anything else (400 = torchaudio's own default, odd
+    sizes) by direct DFT: every flag, the stand-alone STFT stage included."""
     g = dict(BASE, n_fft=n_fft, win_length=min(400, n_fft), hop_length=max(16, n_fft // 4), n_mels=min(64, n_fft // 4))
     g["n_mfcc"] = min(13, g["n_mels"])
     kw = {"use_mfcc": True, **SHIPPED, **flags}
@@ -229,7 +233,7 @@ def test_other_power_of_two_n_fft_with_flags(n_fft, flags):
     f = pre.featurize_batch(w.cuda(), normalize=True)
     ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g), **kw)
     nm = g["n_mels"]
-    assert f.shape == ref.shape == (4, pre.get_num_features(), 1 + 12800 // g["hop_length"])
+    assert f.shape == ref.shape == (4, pre.get_num_features(), 1 + (12800 - n_fft % 2) // g["hop_length"])
     nbase = nm + ((2 * g["n_mfcc"] + (g["n_mfcc"] if kw["use_delta_delta"] else 0)) if kw["use_mfcc"] else 0)
     mel, rel = errors(f[:, :nbase], ref[:, :nbase], nm)
     cerr = (f[:, nbase:].cpu() - ref[:, nbase:]).abs().max().item() if kw["use_spectral_contrast"] else 0.0
@@ -240,5 +244,5 @@ def test_other_power_of_two_n_fft_with_flags(n_fft, flags):
     assert spec.shape == sref.shape == (4, n_fft // 2 + 1, f.shape[2])
     scale = sref.amax(dim=1, keepdim=True).clamp(min=1e-20)
     assert ((spec - sref).abs() / scale).max().item() < 5e-6
-    with pytest.raises(ValueError, match="powers of two"):
-        cda.AudioPreprocessor(n_fft=400, **SHIPPED)
+    with pytest.raises(ValueError, match="16..2048"):
+        cda.AudioPreprocessor(n_fft=4096, **SHIPPED)

@@ -122,7 +122,7 @@ def test_featuriser_random_geometries_and_flags():
     rng = np.random.default_rng(2026)
     for case in range(40):
         sr = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100]))
-        n_fft = int(rng.choice([128, 256, 512, 512, 1024, 2048]))
+        n_fft = int(rng.choice([128, 256, 512, 512, 1024, 2048, 400, 300, 257, 1000]))
         win = int(rng.integers(max(8, n_fft // 8), n_fft + 1))
         hop = int(rng.integers(max(4, n_fft // 16), n_fft + 40))
         n_mels = int(rng.choice([13, 32, 40, 64, 80, 96, 128]))

@@ -61,7 +61,7 @@ def test_preprocessor_interface_and_errors():
         cda.AudioPreprocessor(**{**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 40})
     assert cda.AudioPreprocessor(use_spectral_contrast=False, use_delta_delta=False).get_num_features() == 90   # PCEN on
     with pytest.raises(ValueError, match="n_fft"):
-        cda.AudioPreprocessor(n_fft=400, **SHIPPED)
+        cda.AudioPreprocessor(n_fft=4096, **SHIPPED)
     with pytest.raises(ValueError, match="expected"):
         p.extract_features(torch.zeros(8000))                # (N,): the reference takes (1, N); any N is accepted
     same = torch.zeros(1, 16000)

@@ -118,6 +118,8 @@ GEOMETRIES = {     # AudioPreprocessor(...) constructor calls the generic HIP pa
     "nfft256": dict(n_fft=256, win_length=256, hop_length=128),
     "nfft1024_win400": dict(n_fft=1024),
     "nfft2048_sr44100": dict(n_fft=2048, win_length=2048, hop_length=512, sample_rate=44100, f_max=16000.0, n_mels=128),
+    "nfft400_torchaudio_default": dict(n_fft=400, win_length=400, hop_length=200),
+    "nfft301_odd": dict(n_fft=301, win_length=200, hop_length=100, n_mels=40),
 }
 
 
@@ -128,7 +130,7 @@ def geometry_clip(seed: int, n: int) -> np.ndarray:
 
 
 @pytest.mark.parametrize("name", ["mels40_fmax8k", "mels80_mfcc20", "mels128_mfcc40_fmin20", "half_second", "two_seconds",
-                                  "hop128_win512", "nfft256", "nfft1024_win400", "nfft2048_sr44100"])
+                                  "hop128_win512", "nfft256", "nfft1024_win400", "nfft2048_sr44100", "nfft400_torchaudio_default"])
 def test_generic_geometry_restatement_against_third_party_code(name):
     """The restatement at the constructor's OTHER geometries against transformers + scipy (code the builder did not write):
     the parameters n_mels / n_mfcc / f_min / f_max / hop / win / segment length are honoured the way independent code
@@ -163,7 +165,7 @@ def test_generic_geometry_restatement_against_float64(name):
         f64 = dft64.features(x, g["sample_rate"], g["n_mels"], g["hop_length"], g["win_length"], g["f_min"], g["f_max"],
                              g["n_mfcc"], g["n_fft"])
         nm = g["n_mels"]
-        assert f32.shape == f64.shape == (nm + 2 * g["n_mfcc"], 1 + n // g["hop_length"])
+        assert f32.shape == f64.shape == (nm + 2 * g["n_mfcc"], 1 + (n - g["n_fft"] % 2) // g["hop_length"])
         assert np.abs(f32[:nm] - f64[:nm]).max() < 2e-5      # float32 filterbank taps differ from float64 ones by 1e-5
         assert np.abs(f32[nm:] - f64[nm:]).max() < 5e-5
 

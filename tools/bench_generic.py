@@ -17,6 +17,9 @@ CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
          ("2 s windows (201 frames)", dict(segment_duration=2.0), 2048),
          ("0.5 s windows (51 frames)", dict(segment_duration=0.5), 8192),
          ("22.05 kHz, hop 220, win 441", dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441), 4096),
+         ("n_fft 1024, win 400 (radix-2 Stockham kernel)", dict(n_fft=1024), 4096),
+         ("n_fft 256, win 256, hop 128", dict(n_fft=256, win_length=256, hop_length=128), 4096),
+         ("n_fft 400 = win (direct DFT)", dict(n_fft=400), 4096),
          ("2 s, all constructor defaults but 4 contrast bands", dict(segment_duration=2.0, use_pcen=True, use_pre_emphasis=True,
                                                                     use_delta_delta=True, use_spectral_contrast=True,
                                                                     n_contrast_bands=4), 2048)]
@@ -25,7 +28,7 @@ for name, kw, b in CASES:
     geom = {k: v for k, v in kw.items() if k not in flags}
     pre = cda.AudioPreprocessor(device="cuda", **geom, **flags)
     w = [torch.randn(b, pre.segment_samples, device="cuda") * 0.1 for _ in range(2)]
-    out = torch.empty((b, pre.get_num_features(), pre.get_expected_time_frames()), device="cuda")
+    out = torch.empty((b, pre.get_num_features(), pre._frames(pre.segment_samples)), device="cuda")
     for i in range(5):
         pre.featurize_batch(w[i % 2], normalize=True, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
