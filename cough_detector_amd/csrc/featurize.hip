@@ -204,7 +204,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         }
     };
     float2 raw[16];
-    if constexpr (!PRE_EMPH) load_group(wave, raw);
+    load_group(wave, raw);
 
     K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
     for (int g = wave; g < NGROUP; g += WAVES) {
@@ -221,25 +221,41 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));   // one v_max3_f32 with |.| modifiers
                 a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
             }
-            // the raw registers are free again: the next group's samples start moving now and land while
-            // this group's FFT / mel / log run
-            if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
         }
         if constexpr (PRE_EMPH) {
-            // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the
-            // reflect padding as the reference does; rare flag -> simple re-gather, no FMA contraction
+            // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the reflect padding as the
+            // reference does; no FMA contraction (mul_rn, __fsub_rn).  The peak is of x, not of the emphasised signal.
+            if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
+                // x[i0 - 1] is the second sample of the lane to the left (row_ror:1); lane 0 takes lane 15's pair of the
+                // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does)
+                float carry = 0.f;
 #pragma unroll
-            for (int n1 = 1; n1 < 15; ++n1) {
-                int i0 = s0 + 32 * n1, i1 = i0 + 1;
-                i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
-                i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
-                const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
-                const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
-                const float x0 = x[i0], x1 = x[i1];
-                peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));   // the peak is of x, not of the emphasised signal
-                a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
+                for (int n1 = 1; n1 < 15; ++n1) {
+                    const float rot = dpp_mov<0x121>(raw[n1].y);
+                    const float left = j == 0 ? carry : rot;
+                    carry = rot;
+                    const float x0 = raw[n1].x, x1 = raw[n1].y;
+                    peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
+                    a[n1] = make_float2(__fsub_rn(x0, mul_rn(pre_coef, left)) * w_re[n1],
+                                        __fsub_rn(x1, mul_rn(pre_coef, x0)) * w_im[n1]);
+                }
+            } else {   // reflected edge frames (3 of 26 groups): the left neighbour in CLIP order, by re-gather
+#pragma unroll
+                for (int n1 = 1; n1 < 15; ++n1) {
+                    int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                    i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                    i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                    const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
+                    const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
+                    const float x0 = raw[n1].x, x1 = raw[n1].y;
+                    peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
+                    a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
+                }
             }
         }
+        // the raw registers are free again: the next group's samples start moving now and land while
+        // this group's FFT / mel / log run
+        if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
         K1_MARK("PHASE P1 radix-16 #1");
         dft16(a);
         K1_MARK("PHASE P1 twiddle (LDS table) complex multiply");

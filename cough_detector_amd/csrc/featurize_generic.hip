@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "contrast_rank.h"
 #include "fft256.h"
 #include "internal.h"
 
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void gen_delta_kernel(float* __restrict__ feat
 __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restrict__ P, const float* __restrict__ M, int T, int nfreq,
                                                           ContrastCfg cfg, const float* __restrict__ freqs, float nyquist,
                                                           float* __restrict__ feat, int nfeat, int row0) {
-    __shared__ float band[G_CT_BINS * G_TT];
+    __shared__ __attribute__((aligned(16))) float4 band4[G_CT_BINS / 4 * G_TT];   // quad-planar, contrast_rank.h
     const int lane = threadIdx.x;
     const long long clip = blockIdx.y;
     const int t = blockIdx.x * G_TT + lane;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restric
         int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
         if (high <= low) high = low + 1;
         if (high > nfreq) high = nfreq;
-        const int nb = high - low;
+        const int nb = high - low, nq = (nb + 3) >> 2;
         int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
         if (top_idx < 1) top_idx = 1;
         if (bot_idx < 1) bot_idx = 1;
@@ -449,22 +450,24 @@ __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restric
         const int FT = nb <= G_CT_BINS ? G_TT : nb <= 2 * G_CT_BINS ? G_TT / 2 : nb <= 4 * G_CT_BINS ? G_TT / 4 : G_TT / 8;
         for (int sub = 0; sub < G_TT / FT; ++sub) {
             const int ts = blockIdx.x * G_TT + sub * FT + lane;
-            __syncthreads();
-            if (lane < FT)
-                for (int e = 0; e < nb; ++e) band[e * FT + lane] = ts < T ? Pc[(long long)(low + e) * T + ts] : 0.f;
+            if (blockIdx.x * G_TT + sub * FT >= T) break;   // wave-uniform: nothing left of this tile
             __syncthreads();
             if (lane < FT) {
-                float top = 0.f, bot = 0.f;
-                for (int e = 0; e < nb; ++e) {
-                    const float v = band[e * FT + lane];
-                    int rank = 0;
-                    for (int q = 0; q < nb; ++q) {
-                        const float u = band[q * FT + lane];
-                        rank += (u < v || (u == v && q < e)) ? 1 : 0;
-                    }
-                    if (rank >= top_idx) top += v;
-                    if (rank < bot_idx) bot += v;
+                const float nan = __builtin_nanf("");
+                for (int q = 0; q < nq; ++q) {
+                    const float* src = Pc + (long long)(low + 4 * q) * T + ts;
+                    float4 u;
+                    u.x = ts < T ? src[0] : 0.f;
+                    u.y = 4 * q + 1 < nb ? (ts < T ? src[T] : 0.f) : nan;
+                    u.z = 4 * q + 2 < nb ? (ts < T ? src[2LL * T] : 0.f) : nan;
+                    u.w = 4 * q + 3 < nb ? (ts < T ? src[3LL * T] : 0.f) : nan;
+                    band4[q * FT + lane] = u;
                 }
+            }
+            __syncthreads();
+            if (lane < FT) {
+                float top, bot;
+                contrast_band_sums(band4, FT, lane, nb, top_idx, bot_idx, top, bot);
                 const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
                 const float valleys = bot / float(bot_idx);
                 if (ts < T) o[(long long)i * T + ts] = log1pf(peaks) - log1pf(valleys);

@@ -18,6 +18,7 @@
 // the same 8 butterflies.  (The round-1/2 kernel -- one 4-wave workgroup per (clip, frame chunk), sibling chunks' row
 // fragments meeting in L2, 0.2445 ms = 35 % -- is in the git history; profiles/r03_stft_experiments.txt has the A/B.)
 #include "common.h"
+#include "contrast_rank.h"
 #include "fft256.h"
 #include "internal.h"
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __res
                                                              const float* __restrict__ wav, long long wav_stride,
                                                              float* __restrict__ feat, int nfeat, int row0,
                                                              ContrastCfg cfg, int normalize) {
-    __shared__ float band[CT_MAX_BINS * NFRAMES];
+    extern __shared__ __attribute__((aligned(16))) float4 band4[];   // [quads of the widest band][NFRAMES], contrast_rank.h
     __shared__ float cr[(COUGH_MAX_CONTRAST_BANDS + 1) * NFRAMES];
     __shared__ float red[2];
     const int tid = threadIdx.x;
@@ -352,25 +353,25 @@ __global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __res
         int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
         if (high <= low) high = low + 1;
         if (high > NFREQ) high = NFREQ;
-        const int nb = high - low;
+        const int nb = high - low, nq = (nb + 3) >> 2;
         __syncthreads();
-        for (int idx = tid; idx < nb * NFRAMES; idx += CT_THREADS) band[idx] = P[low * NFRAMES + idx] * scale;
+        if (tid < NFRAMES)
+            for (int q = 0; q < nq; ++q) {
+                const float* src = P + (low + 4 * q) * NFRAMES + tid;
+                float4 u;
+                u.x = src[0] * scale;
+                u.y = 4 * q + 1 < nb ? src[NFRAMES] * scale : __builtin_nanf("");
+                u.z = 4 * q + 2 < nb ? src[2 * NFRAMES] * scale : __builtin_nanf("");
+                u.w = 4 * q + 3 < nb ? src[3 * NFRAMES] * scale : __builtin_nanf("");
+                band4[q * NFRAMES + tid] = u;
+            }
         __syncthreads();
         if (tid < NFRAMES) {
             int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
             if (top_idx < 1) top_idx = 1;
             if (bot_idx < 1) bot_idx = 1;
-            float top = 0.f, bot = 0.f;
-            for (int e = 0; e < nb; ++e) {
-                const float v = band[e * NFRAMES + tid];
-                int rank = 0;
-                for (int q = 0; q < nb; ++q) {
-                    const float u = band[q * NFRAMES + tid];
-                    rank += (u < v || (u == v && q < e)) ? 1 : 0;
-                }
-                if (rank >= top_idx) top += v;
-                if (rank < bot_idx) bot += v;
-            }
+            float top, bot;
+            contrast_band_sums(band4, NFRAMES, tid, nb, top_idx, bot_idx, top, bot);
             const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
             const float valleys = bot / float(bot_idx);
             cr[i * NFRAMES + tid] = log1pf(peaks) - log1pf(valleys);
@@ -421,12 +422,19 @@ int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wa
     const size_t half = contrast_workspace_bytes(n_clips) / 2;
     float* pw = static_cast<float*>(d_workspace);
     float* mg = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + half);
+    int widest = 1;
+    for (int i = 0; i < cfg.n_bands; ++i) {
+        const int lo = cfg.edges[i], hi = cfg.edges[i + 1] > NFREQ ? NFREQ : cfg.edges[i + 1];
+        if (hi - lo > widest) widest = hi - lo;
+    }
+    COUGH_REQUIRE(widest <= CT_MAX_BINS, COUGH_EUNSUPPORTED, "spectral-contrast band of %d bins (<= %d)", widest, CT_MAX_BINS);
+    const size_t ct_lds = size_t((widest + 3) / 4) * NFRAMES * sizeof(float4);   // <= 51 712 B
     for (int c0 = 0; c0 < n_clips; c0 += CT_SUB_BATCH) {
         const int nc = n_clips - c0 < CT_SUB_BATCH ? n_clips - c0 : CT_SUB_BATCH;
         const float* w = d_wav + (long long)c0 * wav_stride;
         if (int e = launch_stft(v, w, wav_stride, pw, nc, 0, stream)) return e;
         if (int e = launch_stft(v, w, wav_stride, mg, nc, COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW, stream)) return e;
-        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), 0, stream, pw, mg, w, wav_stride,
+        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), ct_lds, stream, pw, mg, w, wav_stride,
                            d_feat + (long long)c0 * nfeat * NFRAMES, nfeat, row0, cfg, normalize);
         COUGH_HIP_CHECK(hipGetLastError());
     }
