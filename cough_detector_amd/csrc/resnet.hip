@@ -992,9 +992,18 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
 // clips per workgroup of block 1 at the 13x13 / 14x13 inputs: 1 (48-52 KB of LDS, three workgroups per CU; two clips per
 // workgroup = 95-102 KB, one workgroup per CU, measured the same: profiles/r04_heights.txt)
 constexpr int RBX_G_TALL = 1;
-// block-input geometries resblock_x3_kernel is instantiated for (block index, rows, columns)
+// block-input geometries resblock_x3_kernel is instantiated for (block index, rows, columns): every feature image the
+// reference's flags produce at 99..102 frames.  Image rows -> block-0 rows -> block-1 rows:
+//   64 (use_mfcc = False) 16 -> 8 | 65..68 (+ contrast rows) 17 -> 9 | 87..90 (shipped) 22 -> 11 | 91..94 (+ contrast rows) 23 -> 12 |
+//   95..98 24 -> 12 | 103..106 (delta-delta on) 26 -> 13 | 107..110 (+ contrast rows: the constructor's defaults) 27 -> 14
+#define RBX_BLOCK0_ROWS(X) X(16) X(17) X(22) X(23) X(24) X(26) X(27)
+#define RBX_BLOCK1_ROWS(X) X(8) X(9) X(11) X(12) X(13) X(14)
+// clips per workgroup of block 1: 2 up to 12 rows (the shipped 11x13: 95 KB of LDS, one workgroup per CU), RBX_G_TALL above
+constexpr int rbx_block1_clips(int xh) { return xh <= 12 ? 2 : RBX_G_TALL; }
 inline bool rbx_compiled(int blk, int xh, int xw) {
-    return blk == 0 ? (xw == 25 && (xh == 22 || xh == 26 || xh == 27)) : (xw == 13 && (xh == 11 || xh == 13 || xh == 14));
+#define RBX_HAS(R) || xh == R
+    return blk == 0 ? (xw == 25 && (false RBX_BLOCK0_ROWS(RBX_HAS))) : (xw == 13 && (false RBX_BLOCK1_ROWS(RBX_HAS)));
+#undef RBX_HAS
 }
 
 template <int CIN, int COUT, int G, int XH, int XW>
@@ -1055,12 +1064,12 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                     if (stem_done) ra.out = nullptr;   // pipeline: nobody reads a3
                     head_done = true;
                 }
-                if (i == 0 && k.xh == 22) rbx_launch<32, 64, 1, 22, 25>(n, st, ra);
-                else if (i == 0 && k.xh == 26) rbx_launch<32, 64, 1, 26, 25>(n, st, ra);
-                else if (i == 0) rbx_launch<32, 64, 1, 27, 25>(n, st, ra);
-                else if (k.xh == 11) rbx_launch<64, 128, 2, 11, 13>(n, st, ra);
-                else if (k.xh == 13) rbx_launch<64, 128, RBX_G_TALL, 13, 13>(n, st, ra);
-                else rbx_launch<64, 128, RBX_G_TALL, 14, 13>(n, st, ra);
+#define RBX_GO0(R) if (i == 0 && k.xh == R) rbx_launch<32, 64, 1, R, 25>(n, st, ra);
+#define RBX_GO1(R) if (i == 1 && k.xh == R) rbx_launch<64, 128, rbx_block1_clips(R), R, 13>(n, st, ra);
+                RBX_BLOCK0_ROWS(RBX_GO0)
+                RBX_BLOCK1_ROWS(RBX_GO1)
+#undef RBX_GO0
+#undef RBX_GO1
                 COUGH_HIP_CHECK(hipGetLastError());
                 continue;
             }
@@ -1207,12 +1216,11 @@ extern "C" int cough_resnet_create(cough_resnet** out, const cough_resnet_weight
         }
     }
     if (!err && dtype == COUGH_DTYPE_BF16X3) {   // more than 64 KB of dynamic LDS
-        const void* fused[] = {reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 22, 25>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 26, 25>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, 27, 25>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, 2, 11, 13>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, RBX_G_TALL, 13, 13>),
-                               reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, RBX_G_TALL, 14, 13>)};
+#define RBX_FN0(R) reinterpret_cast<const void*>(resblock_x3_kernel<32, 64, 1, R, 25>),
+#define RBX_FN1(R) reinterpret_cast<const void*>(resblock_x3_kernel<64, 128, rbx_block1_clips(R), R, 13>),
+        const void* fused[] = {RBX_BLOCK0_ROWS(RBX_FN0) RBX_BLOCK1_ROWS(RBX_FN1)};
+#undef RBX_FN0
+#undef RBX_FN1
         hipError_t e = hipSuccess;
         for (const void* fn : fused)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -43,7 +43,18 @@ def main():
     x103 = featurizer.extract_features_batch(wav, use_pre_emphasis=True, use_pcen=True, use_delta_delta=True).unsqueeze(1)
     noise = torch.randn(N, 1, 7, x103.shape[-1], generator=torch.Generator().manual_seed(110))
     out = {}
-    for name, x in (("h103", x103.contiguous()), ("h110", torch.cat([x103, noise], dim=2).contiguous())):
+    # the heights of the remaining flag sets (8 clips each): use_mfcc=False (64 mel rows), + 3 contrast bands + centroid
+    # (68), shipped + 1 band + centroid (92), shipped + 4 bands + centroid (95: the most bands whose rows are not NaN)
+    off = dict(use_pre_emphasis=False, use_pcen=False, use_delta_delta=False)
+    more = [("h64", dict(off, use_mfcc=False)),
+            ("h68", dict(off, use_mfcc=False, use_spectral_contrast=True, n_contrast_bands=3)),
+            ("h92", dict(off, use_spectral_contrast=True, n_contrast_bands=1)),
+            ("h95", dict(off, use_spectral_contrast=True, n_contrast_bands=4))]
+    cases = [("h103", x103.contiguous()), ("h110", torch.cat([x103, noise], dim=2).contiguous())]
+    for name, kw in more:
+        cases.append((name, featurizer.extract_features_batch(wav[:8], **kw).unsqueeze(1).contiguous()))
+    for name, x in cases:
+        n = x.shape[0]
         with torch.no_grad():
             # the head of resnet_golden.npz was calibrated on 90-row log-mel images; re-calibrate it on THIS input set
             # the same way (class-margin std 2.5, both classes present) -- stored per height as fc.2.weight / fc.2.bias
@@ -52,7 +63,7 @@ def main():
             net.fc[2].weight.data.mul_(2.5 / (l[:, 1] - l[:, 0]).std())
             net.fc[2].bias.data.sub_(net(x).mean(dim=0))
             d = (net(x)[:, 1] - net(x)[:, 0]).sort().values
-            net.fc[2].bias.data[1] -= 0.5 * (d[N // 2 - 1] + d[N // 2])
+            net.fc[2].bias.data[1] -= 0.5 * (d[n // 2 - 1] + d[n // 2])
             a1 = net.conv1(x)
             a2 = net.res_blocks[0](a1)
             a3 = net.res_blocks[1](a2)

@@ -42,14 +42,14 @@ def resnet_golden():
 
 @pytest.fixture(scope="session")
 def resnet_heights_golden(resnet_golden):
-    """{"h103" | "h110": (state_dict, vectors)}: the reference module on 103- and 110-row images
+    """{"h64" | "h68" | "h92" | "h95" | "h103" | "h110": (state_dict, vectors)}: the reference module on images of those heights
     (oracle/make_golden_heights.py); the conv weights of resnet_golden.npz, the head re-calibrated per height."""
     import numpy as np
     import torch
     base_sd, _ = resnet_golden
     g = np.load(os.path.join(GOLDEN, "resnet_heights_golden.npz"))
     out = {}
-    for name in ("h103", "h110"):
+    for name in ("h64", "h68", "h92", "h95", "h103", "h110"):
         sd = dict(base_sd)
         sd["fc.2.weight"] = torch.from_numpy(g[name + ".fc.2.weight"])
         sd["fc.2.bias"] = torch.from_numpy(g[name + ".fc.2.bias"])

@@ -60,7 +60,8 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
     assert 0.0 < ev[0].elapsed_time(ev[1]) < 50.0
 
 
-@pytest.mark.parametrize("flags,rows", [(dict(use_delta_delta=True), 103),
+@pytest.mark.parametrize("flags,rows", [(dict(use_delta_delta=True), 103), (dict(use_mfcc=False), 64),
+                                        (dict(use_spectral_contrast=True, n_contrast_bands=4), 95),
                                         (dict(use_delta_delta=True, use_pre_emphasis=True, use_pcen=True,
                                               use_spectral_contrast=True, n_contrast_bands=4), 108)])
 def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(resnet_heights_golden, flags, rows):
@@ -70,7 +71,7 @@ def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(re
     import warnings
     sd, _ = resnet_heights_golden["h103"]
     w = synth_batch(900, 21, peak_normalize=False) * 0.5
-    kw = {**SHIPPED, **flags}
+    kw = {"use_mfcc": True, **SHIPPED, **flags}
     pre = cda.AudioPreprocessor(device="cuda", **kw)
     model = cda.create_model("residual", n_mels=rows, num_classes=2, in_channels=1, compute_dtype="bf16x3")
     model.load_state_dict(sd)

@@ -284,9 +284,10 @@ def test_effective_dtype_reports_the_kernels_that_run():
     forward, tests/test_gpu_fuzz.py), not silently replaced."""
     import cough_detector_amd as cda
     m = cda.create_model("residual", n_mels=90, compute_dtype="bf16x3")
-    assert m.compute_dtype == "bf16x3" and m.effective_dtype() == "bf16x3" and m.effective_dtype(64, 101) == "fp32"
+    assert m.compute_dtype == "bf16x3" and m.effective_dtype() == "bf16x3" and m.effective_dtype(80, 101) == "fp32"
     assert m.effective_dtype(103, 101) == "bf16x3" and m.effective_dtype(110, 101) == "bf16x3"     # the reference's own flags
-    assert m.effective_dtype(95, 101) == "fp32" and m.effective_dtype(103, 201) == "fp32"
+    assert m.effective_dtype(100, 101) == "fp32" and m.effective_dtype(103, 201) == "fp32"
+    assert all(m.effective_dtype(h, 101) == "bf16x3" for h in (64, 66, 67, 68, 92, 93, 94, 95))   # use_mfcc=False / 1..4 contrast bands
     assert all(m.effective_dtype(h, 101) == "bf16x3" for h in (105, 106, 107, 108, 109))   # + 1..5 contrast bands
     wide = cda.CoughDetectorResidual(channels=(16, 24, 40), compute_dtype="bf16x3")
     assert wide.effective_dtype() == "fp32" and wide.compute_dtype == "bf16x3"

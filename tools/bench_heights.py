@@ -14,7 +14,7 @@ bound_torch_threads()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sd = synth.random_state_dict(seed=3)
 print(f"lib {os.environ.get('COUGH_AMD_LIB', 'default')}, B = {B}")
-for h in (90, 103, 110):
+for h in (64, 90, 95, 103, 110):
     xs = [torch.rand(B, 1, h, 101, device="cuda") for _ in range(3)]
     row = []
     for dtype in ("fp32", "bf16x3"):
