@@ -350,12 +350,16 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             p[k] = (u >= 0 && u < NFRAMES) ? exp2f((melbuf[m * NFRAMES + u] - shift) * 0.33219280948873623f) : 0.f;
         }
         float lmin = INFINITY, lmax = -INFINITY;
+        float s2[35];   // pair sums shared by neighbouring windows: 5 adds per window instead of 10
+#pragma unroll
+        for (int k = 0; k < 35; ++k) s2[k] = p[k] + p[k + 1];
 #pragma unroll
         for (int k = 0; k < 26; ++k) {
-            float sm = 0.f;
-#pragma unroll
-            for (int q = 0; q < 10; ++q) sm += p[k + q];
-            pv[k] = sqrtf(p[k + 5] / __powf(1e-6f + sm * 0.1f, 0.98f) + 2.0f) - 1.41421356237309515f;
+            const float sm = ((s2[k] + s2[k + 2]) + (s2[k + 4] + s2[k + 6])) + s2[k + 8];
+            // mel / (eps + smooth)^0.98 as mel * 2^(-0.98 log2(eps + smooth)): hardware log2 / exp2 / sqrt (1 ulp each; the
+            // argument eps + smooth >= 1e-6 is a normal number, the result feeds a min-max normalisation)
+            const float gain = __builtin_amdgcn_exp2f(-0.98f * __builtin_amdgcn_logf(1e-6f + sm * 0.1f));
+            pv[k] = __builtin_amdgcn_sqrtf(fmaf(p[k + 5], gain, 2.0f)) - 1.41421356237309515f;
             if (t0 + k < t1) { lmin = fminf(lmin, pv[k]); lmax = fmaxf(lmax, pv[k]); }
         }
         const float mn = -block_max(-lmin, red, tid), mx = block_max(lmax, red, tid);

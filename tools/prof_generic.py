@@ -16,6 +16,7 @@ OFF = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_sp
 CASES = {"defaults2s": (dict(segment_duration=2.0, use_pcen=True, use_pre_emphasis=True, use_delta_delta=True,
                              use_spectral_contrast=True, n_contrast_bands=4), 2048),
          "defaults1s": (dict(), 4096),
+         "contrast4": (dict(OFF, use_spectral_contrast=True, n_contrast_bands=4), 4096),
          "pcen1s": (dict(OFF, use_delta_delta=True, use_pcen=True, use_pre_emphasis=True), 4096),
          "fmax8k": (dict(f_max=8000.0, **OFF), 4096),
          "nfft1024": (dict(n_fft=1024, **OFF), 4096),
