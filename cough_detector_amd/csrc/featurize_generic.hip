@@ -248,26 +248,45 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
     }
 }
 
-// ------------------------------------------------------------------------------------------------ STFT, ANY n_fft (direct DFT)
+// ------------------------------------------------------------------------------------------------ STFT, ANY n_fft (DFT as a matrix product)
 // An n_fft that is not a power of two (torchaudio's own default is 400): X[k] = sum_n x[n] w[n] e^{-2 pi i k n / n_fft} evaluated
-// directly -- one wave per frame, the windowed frame and the n_fft twiddles (computed in double on the host) in LDS, lane =
-// bin, the twiddle index (k n) mod n_fft stepped incrementally, four interleaved partial sums per bin (shorter error chains).
-// O(n_fft^2) per frame: a generality fallback (16 M FMA per 1 s clip at n_fft = 400), not a throughput path.
+// directly -- on the matrix cores in EXACT f32 (v_mfma_f32_32x32x2_f32: an fmaf chain per output, bit for bit what a VALU loop
+// would give, at the VALU's peak rate but with every operand reused 32 times out of registers).  The real input halves the sum:
+//   Re X[k] =  sum_{n = 0}^{n_fft / 2} s[n] cos(2 pi k n / n_fft),  s[n] = x[n] + x[n_fft - n]  (s[0] = x[0]; s[n_fft / 2] = x[n_fft / 2])
+//   Im X[k] = -sum d[n] sin(2 pi k n / n_fft),                      d[n] = x[n] - x[n_fft - n]  (0 at the self-paired samples)
+// i.e. two products [32 frames x n] . [n x bins] against constant tables (cos and -sin of (k n mod n_fft), computed in double on
+// the host, zero-padded to whole tiles).  A workgroup = 32 frames of one clip; s / d are staged 64 values of n at a time
+// ([n][32 frames]: the A fragment is one conflict-free ds_read_b32), the table rows stream from L2 (the B fragment is one
+// coalesced 128-byte row per half-wave); a wave owns two 32-bin tiles per pass (64 accumulator registers), 8 tiles per pass.
+// The spectrum tile [32][bins + 1] collects the passes for the mel projection / the frame-major store.  4 M FMA per 1 s clip at
+// n_fft = 400: the generality fallback, not a throughput path.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int G_DFT_M = 32, G_DFT_KC = 64;
+struct GenDft {
+    // cos(2 pi (k n mod n_fft) / n_fft) and -sin(...) in FRAGMENT order: [bin tile][group of 8 n][lane = (n & 1) * 32 + bin % 32]
+    // as float4 over n = 8 group + 2 q + (n & 1), q = 0 .. 3 -- one 16-byte load per lane feeds four k-steps, a wave's load is
+    // one contiguous KB; n padded to whole chunks, bins to whole tiles, with zeros
+    const float4* cos_t;
+    const float4* sin_t;
+    int pitch;    // bins rounded up to 32
+    int groups;   // groups of 8 n per tile
+};
+inline size_t dft_lds_bytes(int pitch) { return size_t(2) * G_DFT_KC * G_DFT_M * 4 + size_t(G_DFT_M) * (pitch + 1) * 4; }
+
 template <bool MAG, bool MEL>
 __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
-                                                           int nfft, const float* __restrict__ win /* [nfft] */,
-                                                           const float2* __restrict__ twf /* [nfft]: e^{-2 pi i j / nfft} */,
+                                                           int nfft, const float* __restrict__ win /* [nfft] */, GenDft tab,
                                                            const float* __restrict__ peaks, int pre_emph, float coef,
                                                            float* __restrict__ out, GenMel mel) {
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
-    const int nfreq = nfft / 2 + 1, pad = nfft / 2;
+    const int nfreq = nfft / 2 + 1, pad = nfft / 2, nh = nfft / 2;   // n = 0 .. nh
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float2* tw = reinterpret_cast<float2*>(smem_d);                                   // [nfft]
-    float* xw = reinterpret_cast<float*>(tw + nfft) + size_t(wave) * nfft;            // [4][nfft] windowed frames
-    float* spec = reinterpret_cast<float*>(tw + nfft) + size_t(4) * nfft + size_t(wave) * (nfreq + 1);
-    for (int j = tid; j < nfft; j += 256) tw[j] = twf[j];
+    const int pitch = tab.pitch, n_tiles = pitch >> 5, SP = pitch + 1;
+    float* sp = reinterpret_cast<float*>(smem_d);       // [KC][32] sums of the current chunk
+    float* df = sp + G_DFT_KC * G_DFT_M;                // [KC][32] differences
+    float* spec = df + G_DFT_KC * G_DFT_M;              // [32][pitch + 1]
     const long long clip = blockIdx.y;
-    const int t_raw = blockIdx.x * 4 + wave, t = t_raw < T ? t_raw : T - 1;
+    const int t0 = blockIdx.x * G_DFT_M;
     const float* x = wav + clip * stride;
     const float m = peaks ? peaks[clip] : 0.f;
     const float inv_m = m > 0.f ? 1.0f / m : 1.0f;
@@ -278,38 +297,109 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
         if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));
         return v;
     };
-    const int s0 = hop * t - pad;
-    for (int n = lane; n < nfft; n += 64) xw[n] = value(s0 + n) * win[n];
-    __syncthreads();
-    for (int k = lane; k < nfreq; k += 64) {
-        float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
-        int idx = 0;                                   // (k n) mod nfft
-        for (int n = 0; n < nfft; ++n) {
-            const float2 w = tw[idx];
-            const float v = xw[n];
-            re[n & 3] = fmaf(v, w.x, re[n & 3]);
-            im[n & 3] = fmaf(v, w.y, im[n & 3]);
-            idx += k;
-            if (idx >= nfft) idx -= nfft;
+    const int col = lane & 31, half = lane >> 5;
+    for (int pass0 = 0; pass0 < n_tiles; pass0 += 8) {
+        const int tile_a = pass0 + wave, tile_b = pass0 + 4 + wave;   // wave-uniform
+        const bool has_a = tile_a < n_tiles, has_b = tile_b < n_tiles;
+        f32x16 ra = {}, ia = {}, rb = {}, ib = {};
+        float4 nca = {}, nsa = {}, ncb = {}, nsb = {};
+        auto load_b = [&](int g) {
+            const size_t ia4 = (size_t(tile_a) * tab.groups + g) * 64 + lane;
+            nca = tab.cos_t[ia4];
+            nsa = tab.sin_t[ia4];
+            if (has_b) {
+                const size_t ib4 = (size_t(tile_b) * tab.groups + g) * 64 + lane;
+                ncb = tab.cos_t[ib4];
+                nsb = tab.sin_t[ib4];
+            }
+        };
+        if (has_a) load_b(0);
+        for (int n0 = 0; n0 <= nh; n0 += G_DFT_KC) {
+            __syncthreads();   // the previous chunk has been consumed
+            for (int i = tid; i < G_DFT_KC * G_DFT_M; i += 256) {
+                const int n = n0 + (i >> 5), f = i & 31;
+                float a = 0.f, b = 0.f;
+                bool paired = false;
+                if (n <= nh) {
+                    const int t = t0 + f < T ? t0 + f : T - 1;
+                    const int s0 = hop * t - pad, n2 = nfft - n;
+                    a = value(s0 + n) * win[n];
+                    paired = n > 0 && n2 != n;
+                    if (paired) b = value(s0 + n2) * win[n2];
+                }
+                sp[i] = a + b;
+                df[i] = paired ? a - b : 0.f;
+            }
+            __syncthreads();
+            if (has_a) {
+#pragma unroll 2
+                for (int gi = 0; gi < G_DFT_KC / 8; ++gi) {
+                    const int g = (n0 >> 3) + gi;
+                    const float4 ca = nca, sa = nsa, cb = ncb, sb = nsb;
+                    if (g + 1 < tab.groups) load_b(g + 1);   // the next group's fragments fly while this one is multiplied
+                    const float* as = sp + (8 * gi + half) * G_DFT_M + col;
+                    const float* ad = df + (8 * gi + half) * G_DFT_M + col;
+                    const float s0 = as[0], s1 = as[2 * G_DFT_M], s2 = as[4 * G_DFT_M], s3 = as[6 * G_DFT_M];
+                    const float d0 = ad[0], d1 = ad[2 * G_DFT_M], d2 = ad[4 * G_DFT_M], d3 = ad[6 * G_DFT_M];
+                    ra = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, ca.x, ra, 0, 0, 0);
+                    ia = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, sa.x, ia, 0, 0, 0);
+                    if (has_b) {
+                        rb = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, cb.x, rb, 0, 0, 0);
+                        ib = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, sb.x, ib, 0, 0, 0);
+                    }
+                    ra = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, ca.y, ra, 0, 0, 0);
+                    ia = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, sa.y, ia, 0, 0, 0);
+                    if (has_b) {
+                        rb = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, cb.y, rb, 0, 0, 0);
+                        ib = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, sb.y, ib, 0, 0, 0);
+                    }
+                    ra = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, ca.z, ra, 0, 0, 0);
+                    ia = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, sa.z, ia, 0, 0, 0);
+                    if (has_b) {
+                        rb = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, cb.z, rb, 0, 0, 0);
+                        ib = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, sb.z, ib, 0, 0, 0);
+                    }
+                    ra = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, ca.w, ra, 0, 0, 0);
+                    ia = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, sa.w, ia, 0, 0, 0);
+                    if (has_b) {
+                        rb = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, cb.w, rb, 0, 0, 0);
+                        ib = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, sb.w, ib, 0, 0, 0);
+                    }
+                }
+            }
         }
-        const float xr = (re[0] + re[1]) + (re[2] + re[3]), xi = (im[0] + im[1]) + (im[2] + im[3]);
-        const float pw = xr * xr + xi * xi;
-        spec[k] = MAG ? sqrtf(pw) : pw;
+        // C layout of 32x32: register i of lane l = row 8 (i / 4) + 4 (l / 32) + i % 4 (frame), column l % 32 (bin of the tile)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = 8 * (i >> 2) + 4 * half + (i & 3);
+            if (has_a) {
+                const float p = ra[i] * ra[i] + ia[i] * ia[i];
+                spec[f * SP + tile_a * 32 + col] = MAG ? sqrtf(p) : p;
+            }
+            if (has_b) {
+                const float p = rb[i] * rb[i] + ib[i] * ib[i];
+                spec[f * SP + tile_b * 32 + col] = MAG ? sqrtf(p) : p;
+            }
+        }
     }
-    wave_lds_fence();
-    if (t_raw >= T) return;
+    __syncthreads();
     if constexpr (MEL) {
         float* o = out + clip * (long long)mel.n_mels * T;
-        for (int mb = lane; mb < mel.n_mels; mb += 64) {
+        for (int i = tid; i < mel.n_mels * G_DFT_M; i += 256) {
+            const int mb = i >> 5, f = i & 31;
             const int l = mel.lo[mb], hb = mel.hi[mb];
             const float* wm = mel.w + mel.off[mb];
+            const float* row = spec + f * SP;
             float acc = 0.f;
-            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], spec[k], acc);
-            o[(long long)mb * T + t] = acc;
+            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], row[k], acc);
+            if (t0 + f < T) o[(long long)mb * T + t0 + f] = acc;
         }
     } else {
         float* o = out + clip * (long long)nfreq * T;
-        for (int k = lane; k < nfreq; k += 64) o[(long long)k * T + t] = spec[k];
+        for (int i = tid; i < nfreq * G_DFT_M; i += 256) {
+            const int k = i >> 5, f = i & 31;
+            if (t0 + f < T) o[(long long)k * T + t0 + f] = spec[f * SP + k];
+        }
     }
 }
 
@@ -532,7 +622,7 @@ struct GenFeat {
     const float2* tw256;   // [16][16]            (the 512-point kernels)
     const float2* tw512;   // [128]
     const float2* twn;     // [n_fft / 2 + 1] W_n_fft^k (gen_stft_pow2_kernel)
-    const float2* twf;     // [n_fft] W_n_fft^j, all of them (gen_stft_dft_kernel: n_fft not a power of two)
+    GenDft dft;            // cos / -sin matrices of gen_stft_dft_kernel (n_fft not a power of two; else null)
     const int *mel_lo, *mel_hi, *mel_off;
     const float* mel_w;    // CSR taps
     const float* dct_t;    // [n_mfcc][n_mels]
@@ -552,9 +642,9 @@ void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
     } else {
-        const size_t lds = size_t(g->nfft) * 8 + size_t(4) * g->nfft * 4 + size_t(4) * (g->nfft / 2 + 2) * 4;   // <= 58 KB
-        hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), lds, stream, w, wav_stride, g->N,
-                           g->hop, g->T, g->nfft, win, g->twf, peaks, pre_emph, coef, out, mel);
+        hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((g->T + G_DFT_M - 1) / G_DFT_M, nc), dim3(256),
+                           dft_lds_bytes(g->dft.pitch), stream, w, wav_stride, g->N, g->hop, g->T, g->nfft, win, g->dft, peaks, pre_emph,
+                           coef, out, mel);
     }
 }
 }  // namespace
@@ -578,15 +668,34 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     const int n_mels = cfg->n_mels, n_mfcc = cfg->use_mfcc ? cfg->n_mfcc : 0;   // T.MFCC exists only with use_mfcc (:116-127)
     const double PI = 3.14159265358979323846;
     std::vector<float> win(nfft, 0.f), hann(nfft), freqs(nfreq), dct_t(size_t(n_mfcc) * n_mels), taps;
-    std::vector<float2> tw256(256), tw512(128), twn(nfreq), twf(nfft);
+    std::vector<float2> tw256(256), tw512(128), twn(nfreq);
     std::vector<int> lo(n_mels), hi(n_mels), off(n_mels);
     const int left = (nfft - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
     for (int n = 0; n < cfg->win_length; ++n) win[left + n] = window[n];
     for (int n = 0; n < nfft; ++n) hann[n] = float(0.5 - 0.5 * std::cos(2.0 * PI * double(n) / double(nfft)));
     for (int k = 0; k < nfft; ++k) {
         const double a = -2.0 * PI * double(k) / double(nfft);
-        twf[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
-        if (k < nfreq) twn[k] = twf[k];
+        if (k < nfreq) twn[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+    }
+    // gen_stft_dft_kernel's matrices (n_fft not a power of two): [n rounded up to the chunk][bins rounded up to 32], zero padded
+    const bool use_dft = !(nfft >= 64 && (nfft & (nfft - 1)) == 0);
+    const int dft_pitch = use_dft ? (nfreq + 31) / 32 * 32 : 0;
+    const int dft_rows = use_dft ? (nfft / 2 + 1 + G_DFT_KC - 1) / G_DFT_KC * G_DFT_KC : 0;
+    std::vector<float> dft_cos(size_t(dft_rows) * dft_pitch, 0.f), dft_sin(size_t(dft_rows) * dft_pitch, 0.f);
+    if (use_dft) {
+        std::vector<double> cd(nfft), sd(nfft);
+        for (int j = 0; j < nfft; ++j) {
+            cd[j] = std::cos(2.0 * PI * double(j) / double(nfft));
+            sd[j] = -std::sin(2.0 * PI * double(j) / double(nfft));
+        }
+        const int groups = dft_rows / 8;
+        for (int n = 0; n <= nfft / 2; ++n)
+            for (int k = 0; k < nfreq; ++k) {
+                const int j = int((long long)k * n % nfft);
+                const size_t at = ((size_t(k >> 5) * groups + (n >> 3)) * 64 + (n & 1) * 32 + (k & 31)) * 4 + ((n & 7) >> 1);
+                dft_cos[at] = float(cd[j]);
+                dft_sin[at] = float(sd[j]);
+            }
     }
     for (int jj = 0; jj < 16; ++jj)
         for (int k1 = 0; k1 < 16; ++k1) {
@@ -621,7 +730,8 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     }
     // one device blob
     size_t o_win = 0, o_hann = o_win + align256g(nfft * 4), o_tw256 = o_hann + align256g(nfft * 4),
-           o_tw512 = o_tw256 + align256g(256 * 8), o_twn = o_tw512 + align256g(128 * 8), o_twf = o_twn + align256g(nfreq * 8), o_lo = o_twf + align256g(nfft * 8),
+           o_tw512 = o_tw256 + align256g(256 * 8), o_twn = o_tw512 + align256g(128 * 8), o_dc = o_twn + align256g(nfreq * 8), o_ds = o_dc + align256g(dft_cos.size() * 4),
+           o_lo = o_ds + align256g(dft_sin.size() * 4),
            o_hi = o_lo + align256g(n_mels * 4),
            o_off = o_hi + align256g(n_mels * 4), o_taps = o_off + align256g(n_mels * 4),
            o_dct = o_taps + align256g(taps.size() * 4), o_freqs = o_dct + align256g(dct_t.size() * 4),
@@ -632,7 +742,10 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     std::memcpy(host.data() + o_tw256, tw256.data(), 256 * 8);
     std::memcpy(host.data() + o_tw512, tw512.data(), 128 * 8);
     std::memcpy(host.data() + o_twn, twn.data(), nfreq * 8);
-    std::memcpy(host.data() + o_twf, twf.data(), nfft * 8);
+    if (use_dft) {
+        std::memcpy(host.data() + o_dc, dft_cos.data(), dft_cos.size() * 4);
+        std::memcpy(host.data() + o_ds, dft_sin.data(), dft_sin.size() * 4);
+    }
     std::memcpy(host.data() + o_lo, lo.data(), n_mels * 4);
     std::memcpy(host.data() + o_hi, hi.data(), n_mels * 4);
     std::memcpy(host.data() + o_off, off.data(), n_mels * 4);
@@ -665,22 +778,26 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     g->tw256 = reinterpret_cast<const float2*>(b + o_tw256);
     g->tw512 = reinterpret_cast<const float2*>(b + o_tw512);
     g->twn = reinterpret_cast<const float2*>(b + o_twn);
-    g->twf = reinterpret_cast<const float2*>(b + o_twf);
+    g->dft.cos_t = use_dft ? reinterpret_cast<const float4*>(b + o_dc) : nullptr;
+    g->dft.sin_t = use_dft ? reinterpret_cast<const float4*>(b + o_ds) : nullptr;
+    g->dft.pitch = dft_pitch;
+    g->dft.groups = dft_rows / 8;
     g->mel_lo = reinterpret_cast<const int*>(b + o_lo);
     g->mel_hi = reinterpret_cast<const int*>(b + o_hi);
     g->mel_off = reinterpret_cast<const int*>(b + o_off);
     g->mel_w = reinterpret_cast<const float*>(b + o_taps);
     g->dct_t = reinterpret_cast<const float*>(b + o_dct);
     g->freqs = reinterpret_cast<const float*>(b + o_freqs);
-    if (nfft != G_NFFT) {   // gen_stft_pow2_kernel: 4 waves x (two ping-pong buffers + a spectrum) of dynamic LDS, > 64 KB at 2048
+    if (nfft != G_NFFT) {   // more than 64 KB of dynamic LDS: the Stockham kernel at n_fft = 2048, the DFT kernel above ~ 750
         const void* fns[] = {reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, false>),
                              reinterpret_cast<const void*>(gen_stft_pow2_kernel<false, true>),
                              reinterpret_cast<const void*>(gen_stft_pow2_kernel<true, false>),
                              reinterpret_cast<const void*>(gen_stft_dft_kernel<false, false>),
                              reinterpret_cast<const void*>(gen_stft_dft_kernel<false, true>),
                              reinterpret_cast<const void*>(gen_stft_dft_kernel<true, false>)};
+        const size_t need = pow2_lds_bytes(2048) > dft_lds_bytes(1024) ? pow2_lds_bytes(2048) : dft_lds_bytes(1024);
         for (const void* fn : fns)
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(pow2_lds_bytes(2048))) != hipSuccess) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(need)) != hipSuccess) {
                 set_error("cough_featurizer_create (generic geometry): hipFuncSetAttribute failed");
                 gen_feat_destroy(g);
                 return COUGH_EHIP;
