@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------ STFT, any power-of-two n_fft
 // n_fft in {64 .. 2048} other than 512: one WAVE per frame, the n_fft / 2-point complex FFT of the packed real frame as a
-// radix-2 Stockham autosort (ping-pong between two LDS buffers, twiddles from a table computed in double), then the
+// radix-4 Stockham autosort (ping-pong between two LDS buffers, twiddles from a table computed in double), then the
 // real-input split with W_n_fft^k.  4 frames per workgroup.  Slower than the register radix-16 x radix-16 of the 512-point
 // kernels (the shipped n_fft), and fully general in n_fft.
 template <bool MAG, bool MEL>
@@ -190,6 +190,10 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
     float2* buf0 = reinterpret_cast<float2*>(smem_p) + size_t(wave) * 2 * NC;
     float2* buf1 = buf0 + NC;
     float* spec = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem_p) + size_t(4) * 2 * NC) + size_t(wave) * (nfreq + 1);
+    float2* tws = reinterpret_cast<float2*>(reinterpret_cast<float*>(reinterpret_cast<float2*>(smem_p) + size_t(4) * 2 * NC) +
+                                            size_t(4) * (nfreq + 1));   // [NC + 1] W_nfft^k, shared by the 4 waves
+    for (int k = tid; k <= NC; k += 256) tws[k] = twn[k];
+    __syncthreads();
     const long long clip = blockIdx.y;
     const int t_raw = blockIdx.x * 4 + wave, t = t_raw < T ? t_raw : T - 1;
     const float* x = wav + clip * stride;
@@ -206,17 +210,44 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
     for (int n = lane; n < NC; n += 64)
         buf0[n] = make_float2(value(s0 + 2 * n) * win[2 * n], value(s0 + 2 * n + 1) * win[2 * n + 1]);
     wave_lds_fence();
-    // Stockham autosort, decimation in frequency: stage (l, m), l * m = NC / 2; butterfly b -> (j = b / m, k = b % m)
+    // Stockham autosort, decimation in frequency, radix 4 (one radix-2 stage first when log2(NC) is odd): a stage works on
+    // sub-transforms of length n = NC / s interleaved at stride s; butterfly b -> (p = b / s, q = b % s), twiddles W_n^p =
+    // W_nfft^(2 p s) out of the LDS copy of the table (W_nfft^(k + NC) = -W_nfft^k covers the third twiddle's range)
     float2* src = buf0;
     float2* dst = buf1;
-    for (int l = NC >> 1, mm = 1; l >= 1; l >>= 1, mm <<= 1) {
-        for (int b = lane; b < (NC >> 1); b += 64) {
-            const int j = b / mm, k = b - j * mm;
-            const float2 c0 = src[k + j * mm], c1 = src[k + j * mm + l * mm];
-            const float2 w = twn[2 * j * mm];                      // W_{2l}^j = W_NC^{j m} = W_nfft^{2 j m}
+    int ls = 0;   // log2(s)
+    if (__builtin_ctz(NC) & 1) {
+        const int l = NC >> 1;
+        for (int b = lane; b < l; b += 64) {
+            const float2 c0 = src[b], c1 = src[b + l];
             const float2 d = make_float2(c0.x - c1.x, c0.y - c1.y);
-            dst[k + 2 * j * mm] = make_float2(c0.x + c1.x, c0.y + c1.y);
-            dst[k + 2 * j * mm + mm] = cmul(d, w);
+            dst[2 * b] = make_float2(c0.x + c1.x, c0.y + c1.y);
+            dst[2 * b + 1] = cmul(d, tws[2 * b]);
+        }
+        wave_lds_fence();
+        float2* tmp = src; src = dst; dst = tmp;
+        ls = 1;
+    }
+    for (int n1 = NC >> (ls + 2); n1 >= 1; n1 >>= 2, ls += 2) {
+        const int sm = (1 << ls) - 1;
+        for (int b = lane; b < (NC >> 2); b += 64) {
+            const int pp = b >> ls, q = b & sm;
+            const float2* xin = src + q + (pp << ls);
+            const float2 a = xin[0], bb = xin[n1 << ls], c = xin[(2 * n1) << ls], d = xin[(3 * n1) << ls];
+            const int i1 = (2 * pp) << ls;                          // < NC / 2
+            int i3 = 3 * i1;                                        // < 3 NC / 2
+            const bool neg = i3 >= NC;
+            i3 -= neg ? NC : 0;
+            const float2 w1 = tws[i1], w2 = tws[2 * i1];
+            float2 w3 = tws[i3];
+            if (neg) w3 = make_float2(-w3.x, -w3.y);
+            const float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+            const float2 bpd = make_float2(bb.x + d.x, bb.y + d.y), bmd = make_float2(bb.x - d.x, bb.y - d.y);
+            float2* yo = dst + q + ((4 * pp) << ls);
+            yo[0] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+            yo[1 << ls] = cmul(make_float2(amc.x + bmd.y, amc.y - bmd.x), w1);        // (a - c) - i (b - d)
+            yo[2 << ls] = cmul(make_float2(apc.x - bpd.x, apc.y - bpd.y), w2);
+            yo[3 << ls] = cmul(make_float2(amc.x - bmd.y, amc.y + bmd.x), w3);        // (a - c) + i (b - d)
         }
         wave_lds_fence();
         float2* tmp = src; src = dst; dst = tmp;
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
         const float2 zk = src[k == NC ? 0 : k], zq = src[k == 0 || k == NC ? 0 : NC - k];
         const float ex = 0.5f * (zk.x + zq.x), ey = 0.5f * (zk.y - zq.y);
         const float ox = 0.5f * (zk.y + zq.y), oy = 0.5f * (zq.x - zk.x);
-        const float2 w = twn[k];
+        const float2 w = tws[k];
         const float xr = ex + w.x * ox - w.y * oy, xi = ey + w.x * oy + w.y * ox;
         const float pw = xr * xr + xi * xi;
         spec[k] = MAG ? sqrtf(pw) : pw;
@@ -609,7 +640,7 @@ __global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ in,
 }
 
 size_t align256g(size_t v) { return (v + 255) & ~size_t(255); }
-size_t pow2_lds_bytes(int nfft) { return size_t(4) * 2 * (nfft / 2) * 8 + size_t(4) * (nfft / 2 + 2) * 4; }
+size_t pow2_lds_bytes(int nfft) { return size_t(4) * 2 * (nfft / 2) * 8 + size_t(4) * (nfft / 2 + 2) * 4 + size_t(nfft / 2 + 2) * 8; }
 
 }  // namespace
 

@@ -95,7 +95,7 @@ class AudioPreprocessor:
         # (csrc/featurize_generic.hip) -- the library picks.  What torch / torchaudio would refuse is refused here too.
         if not 16 <= n_fft <= 2048:
             raise ValueError(f"AudioPreprocessor: n_fft={n_fft}: the MI355X path implements n_fft = 16..2048 (512, the "
-                             "reference's default, on the register FFT kernels; other powers of two on a radix-2 kernel; "
+                             "reference's default, on the register FFT kernels; other powers of two on a radix-4 kernel; "
                              "anything else by direct DFT)")
         if not 1 <= win_length <= n_fft:
             raise ValueError(f"AudioPreprocessor: win_length={win_length} must lie in 1..n_fft (torch.stft)")

@@ -52,8 +52,8 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
  * which (with a filterbank of <= 8 taps per band below bin 128, i.e. f_max <= sample_rate / 4) runs on
  * the tuned one-launch kernel; every other geometry runs on a chain of small kernels and NEEDS A
  * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft = 512 (the reference's
- * default) uses the register radix-16 x radix-16 FFT, the other powers of two >= 64 a radix-2 Stockham kernel, every
- * other n_fft (400 = torchaudio's own default, odd sizes) a direct DFT -- exact, O(n_fft^2), about 10x slower; the frame
+ * default) uses the register radix-16 x radix-16 FFT, the other powers of two >= 64 a radix-4 Stockham kernel, every
+ * other n_fft (400 = torchaudio's own default, odd sizes) a direct DFT on the f32 matrix cores -- exact, O(n_fft^2), 2-3x slower; the frame
  * count is torch.stft's, (N - n_fft % 2) / hop_length + 1; n_fft outside 16 .. 2048 returns COUGH_EUNSUPPORTED.
  * Output row order as the reference concatenates (:456-487): mel[0:n_mels]
  * (log-mel or PCEN), MFCC, delta, (delta-delta), (spectral contrast + centroid). */

@@ -17,9 +17,9 @@ CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
          ("2 s windows (201 frames)", dict(segment_duration=2.0), 2048),
          ("0.5 s windows (51 frames)", dict(segment_duration=0.5), 8192),
          ("22.05 kHz, hop 220, win 441", dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441), 4096),
-         ("n_fft 1024, win 400 (radix-2 Stockham kernel)", dict(n_fft=1024), 4096),
+         ("n_fft 1024, win 400 (radix-4 Stockham kernel)", dict(n_fft=1024), 4096),
          ("n_fft 256, win 256, hop 128", dict(n_fft=256, win_length=256, hop_length=128), 4096),
-         ("n_fft 400 = win (direct DFT)", dict(n_fft=400), 4096),
+         ("n_fft 400 = win (DFT on the f32 matrix cores)", dict(n_fft=400), 4096),
          ("2 s, all constructor defaults but 4 contrast bands", dict(segment_duration=2.0, use_pcen=True, use_pre_emphasis=True,
                                                                     use_delta_delta=True, use_spectral_contrast=True,
                                                                     n_contrast_bands=4), 2048)]
