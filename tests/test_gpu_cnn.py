@@ -151,3 +151,13 @@ def test_narrow_channel_tuples_load_under_bf16x3_like_under_fp32():
             err = float((got - ref_model).abs().max())
             print(f"channels {channels} {dtype}: logits max abs err {err:.2e}")
             assert err < LOGIT_TOL
+
+
+@pytest.mark.parametrize("kind,dtype", [("standard", "bf16x3"), ("small", "fp32")])
+def test_conv_stack_batch_beyond_2_gib_of_activations(kind, dtype):
+    """36 000 images in one call: the first block's output alone is 5 GB, so clip offsets must be 64-bit.  Batch invariance:
+    the last 300 logits equal a 300-image call bit for bit."""
+    m = cda.create_model(kind, n_mels=90, compute_dtype=dtype).cuda().eval()
+    x = torch.rand(36000, 1, 90, 101, device="cuda")
+    y = m(x)
+    assert torch.isfinite(y).all() and torch.equal(y[-300:], m(x[-300:]))

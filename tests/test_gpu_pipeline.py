@@ -86,3 +86,25 @@ def test_pipeline_with_the_reference_default_flags_runs_the_split_bf16_blocks(re
     print(f"{rows}-row pipeline: logits max abs err {err:.2e}")
     assert err < LOGIT_TOL
     assert torch.equal(pipe(w.cuda(), normalize=True), logits)
+
+
+def test_pipeline_batch_beyond_2_gib_of_activations(resnet_golden):
+    """40 000 clips in ONE call: the waveforms (2.56 GB), the stem output (2.8 GB) and the feature image (1.45 GB) each pass
+    2^31 bytes, so every clip offset in the kernels has to be 64-bit.  Size-independent property: batch invariance -- the last
+    512 clips (the ones past the 2 GiB marks) equal a 512-clip call bit for bit, and a sample matches the CPU oracle."""
+    sd, _ = resnet_golden
+    B = 40000
+    w = synth.device_clips(7_000_000, B)
+    pre = cda.AudioPreprocessor(device="cuda", **SHIPPED)
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    pipe = cda.CoughPipeline(pre, model.cuda())
+    logits, feats = pipe(w, normalize=True, return_features=True)
+    tail_logits, tail_feats = pipe(w[-512:], normalize=True, return_features=True)
+    assert torch.equal(logits[-512:], tail_logits) and torch.equal(feats[-512:], tail_feats)
+    assert torch.equal(pipe(w, normalize=True), logits)                   # features not materialised: same logits
+    two_step = model(pre.featurize_batch(w, normalize=True).unsqueeze(1))
+    assert torch.equal(two_step, logits)
+    idx = torch.tensor([0, 1, 16383, 16384, 32767, 32768, 33554, 39998, 39999])
+    ref = ores.forward(ofeat.extract_features_batch(w[idx].cpu(), normalize_first=True).unsqueeze(1), sd)
+    assert (logits[idx].cpu() - ref).abs().max().item() < LOGIT_TOL
