@@ -17,7 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcough_amd.so")
 SOURCES = ("api.hip", "featurize.hip", "featurize_generic.hip", "spectrogram.hip", "resnet.hip", "cnn.hip", "stream.hip", "synth.hip")
-CFLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: left alone, -O3 packs adjacent f32 adds / multiplies of the FFT butterflies into v_pk_*_f32, which issue
+# slower than the two scalar operations they replace on gfx950 (same-box A/B: K1 -2.4 %, STFT stage -3.2 %, classifier unchanged;
+# profiles/r04_flag_ab.txt)
+CFLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 FLAGS = CFLAGS + ["-shared"]          # one-shot command line (the diagnostic tools build variants with it)
 
 
@@ -31,6 +34,7 @@ def _hipcc() -> str:
 def _headers_mtime() -> float:
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(HERE, "..", "include", "cough_amd.h"))
+    deps.append(os.path.abspath(__file__))   # the flags live here
     return max(os.path.getmtime(d) for d in deps)
 
 

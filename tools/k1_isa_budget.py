@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--kernel", default="bf16x3", choices=list(KERNELS))
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-DCOUGH_K1_MARKERS", "-c", "-save-temps",
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-fno-slp-vectorize", "-DCOUGH_K1_MARKERS", "-c", "-save-temps",
                os.path.join(ROOT, "cough_detector_amd", "csrc", "featurize.hip"), "-o", os.devnull]
         subprocess.run(cmd, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         text = open(os.path.join(tmp, "featurize-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
