@@ -26,4 +26,5 @@ bash tools/pmc_kernel.sh $TAG/pmc_stft "stft3_kernel" tools/bench_stft.py --laun
 python tools/pmc_to_json.py $OUT/pmc_stft $OUT/stft_pmc.json 4096 stft3 167828 > $OUT/stft_pmc.txt && \
 python tools/bench_models.py > $OUT/bench_models.txt 2>&1 && python tools/bench_models.py --dtypes bf16x3 --iters 20 >> $OUT/bench_models.txt 2>&1 && \
 python tools/bench_heights.py > $OUT/bench_heights.txt 2>&1 && \
+python tools/bench_flags.py > $OUT/bench_flags.txt 2>&1 && python tools/bench_generic.py > $OUT/bench_generic.txt 2>&1 && \
 echo FINAL_PROFILE_OK
