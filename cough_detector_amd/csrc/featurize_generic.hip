@@ -75,6 +75,7 @@ struct GenMel {
     int n_mels;
     const int *lo, *hi, *off;
     const float* w;
+    int n_taps;   // length of w
 };
 template <bool MAG, bool MEL>
 __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
@@ -154,16 +155,36 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
     __syncthreads();
     if constexpr (MEL) {
-        // thread = (frame f of the tile, band m mod 16): bins of a band in ascending order
+        // thread = (frame f of the tile, band m mod 16): bins of a band in ascending order.  The CSR filterbank moves into the
+        // (now free) transpose scratch first when it fits -- a triangular bank has ~2 taps per bin --, so a tap is an LDS read
+        // instead of a dependent global load
+        constexpr int W_CAP = 4 * 4 * G_XFRAME - 3 * G_MAX_MELS;
+        float* wl = xs;
+        int* meta = reinterpret_cast<int*>(xs + W_CAP);   // lo | hi | off
+        const bool staged = mel.n_taps <= W_CAP;
+        if (staged)
+            for (int i = tid; i < mel.n_taps; i += 256) wl[i] = mel.w[i];
+        for (int i = tid; i < mel.n_mels; i += 256) {
+            meta[i] = mel.lo[i];
+            meta[G_MAX_MELS + i] = mel.hi[i];
+            meta[2 * G_MAX_MELS + i] = mel.off[i];
+        }
+        __syncthreads();
         const int f = tid & 15, tt = blockIdx.x * G_FPB + f;
         float* o = out + clip * (long long)mel.n_mels * T;
-        for (int m = tid >> 4; m < mel.n_mels; m += 16) {
-            const int l = mel.lo[m], hb = mel.hi[m];
-            const float* wm = mel.w + mel.off[m];
-            float acc = 0.f;
-            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], otile[k * (G_FPB + 1) + f], acc);
-            if (tt < T) o[(long long)m * T + tt] = acc;
-        }
+        auto project = [&](const float* wbase) {
+            for (int m = tid >> 4; m < mel.n_mels; m += 16) {
+                const int l = meta[m], hb = meta[G_MAX_MELS + m];
+                const float* wm = wbase + meta[2 * G_MAX_MELS + m] - l;
+                const float* col = otile + f;
+                float acc = 0.f;
+#pragma unroll 4
+                for (int k = l; k < hb; ++k) acc = fmaf(wm[k], col[k * (G_FPB + 1)], acc);
+                if (tt < T) o[(long long)m * T + tt] = acc;
+            }
+        };
+        if (staged) project(wl);
+        else project(mel.w);
     } else {
         float* o = out + clip * (long long)G_NFREQ * T;
         for (int idx = tid; idx < G_NFREQ * G_FPB; idx += 256) {
@@ -653,6 +674,7 @@ struct GenFeat {
     const float2* tw256;   // [16][16]            (the 512-point kernels)
     const float2* tw512;   // [128]
     const float2* twn;     // [n_fft / 2 + 1] W_n_fft^k (gen_stft_pow2_kernel)
+    int n_taps;            // length of mel_w
     GenDft dft;            // cos / -sin matrices of gen_stft_dft_kernel (n_fft not a power of two; else null)
     const int *mel_lo, *mel_hi, *mel_off;
     const float* mel_w;    // CSR taps
@@ -817,6 +839,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     g->mel_hi = reinterpret_cast<const int*>(b + o_hi);
     g->mel_off = reinterpret_cast<const int*>(b + o_off);
     g->mel_w = reinterpret_cast<const float*>(b + o_taps);
+    g->n_taps = int(taps.size());
     g->dct_t = reinterpret_cast<const float*>(b + o_dct);
     g->freqs = reinterpret_cast<const float*>(b + o_freqs);
     if (nfft != G_NFFT) {   // more than 64 KB of dynamic LDS: the Stockham kernel at n_fft = 2048, the DFT kernel above ~ 750
@@ -880,7 +903,7 @@ int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, 
     COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_spectrogram: row stride %lld < segment of %d samples", wav_stride, g->N);
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const float* win = full ? g->win_full : g->win;
-    const GenMel none{0, nullptr, nullptr, nullptr, nullptr};
+    const GenMel none{0, nullptr, nullptr, nullptr, nullptr, 0};
     if (mag) gen_launch_stft<true, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
     else gen_launch_stft<false, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
     COUGH_HIP_CHECK(hipGetLastError());
@@ -912,7 +935,7 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, g->N, peaks);
         const dim3 gt((T + G_TT - 1) / G_TT, nc);
         // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
-        const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w}, none{0, nullptr, nullptr, nullptr, nullptr};
+        const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, g->n_taps}, none{0, nullptr, nullptr, nullptr, nullptr, 0};
         gen_launch_stft<false, true>(g, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
         hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
