@@ -358,3 +358,30 @@ def test_spectral_centroid_against_float64_numpy(seed):
     tone = np.sin(2 * np.pi * 1000.0 * np.arange(16000) / 16000.0).astype(np.float32)
     c = F.spectral_centroid(torch.from_numpy(tone)[None])[0].numpy()
     assert np.abs(c[5:95] - 1000.0).max() < 0.5
+
+
+def test_random_geometries_restatement_against_float64():
+    """Seeded fuzz over the constructor's geometry space (sample rate, n_fft incl. sizes that are not powers of two and odd ones,
+    window, hop, mel / MFCC counts, band edges, clip length): the float32 restatement vs the float64 re-derivation."""
+    rng = np.random.default_rng(20260404)
+    worst = 0.0
+    for case in range(16):
+        sr = int(rng.choice([8000, 16000, 22050, 44100]))
+        n_fft = int(rng.choice([128, 200, 256, 301, 400, 512, 1000, 1024]))
+        win = int(rng.integers(max(16, n_fft // 4), n_fft + 1))
+        hop = int(rng.integers(max(8, n_fft // 8), n_fft))
+        n_mels = int(rng.choice([20, 40, 64, 80]))
+        n_mfcc = int(rng.integers(2, min(n_mels, 30) + 1))
+        f_min = float(rng.choice([0.0, 50.0, 300.0]))
+        f_max = float(min(sr / 2, rng.choice([3000.0, 4000.0, 8000.0, sr / 2])))
+        n = int(rng.integers(n_fft, 4 * n_fft + 9000))
+        x = geometry_clip(case, n)
+        g = dict(sample_rate=sr, n_mels=n_mels, hop_length=hop, win_length=win, f_min=f_min, f_max=f_max, n_mfcc=n_mfcc, n_fft=n_fft)
+        f32 = F.extract_features(torch.from_numpy(x)[None], **F.geometry_kwargs(**g))[0].numpy()
+        f64 = dft64.features(x, sr, n_mels, hop, win, f_min, f_max, n_mfcc, n_fft)
+        assert f32.shape == f64.shape == (n_mels + 2 * n_mfcc, 1 + (n - n_fft % 2) // hop), g
+        mel = np.abs(f32[:n_mels] - f64[:n_mels]).max()
+        rest = np.abs(f32[n_mels:] - f64[n_mels:]).max()
+        worst = max(worst, mel, rest)
+        assert mel < 3e-5 and rest < 1e-4, (g, n, mel, rest)
+    print(f"16 random geometries: oracle (f32) vs float64 worst abs {worst:.2e}")
