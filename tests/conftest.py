@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the GPU boxes show 256 logical CPUs under a 16-core cgroup quota: torch's default intra-op pool gets the process
+    # throttled and the CPU oracle legs of the parity tests run 5x slower (same rule as bench.py)
+    from cough_detector_amd.hostcpu import bound_torch_threads
+    bound_torch_threads()
 
 
 def pytest_collection_modifyitems(config, items):
