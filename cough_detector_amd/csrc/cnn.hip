@@ -1153,9 +1153,15 @@ int cnn_run(const cough_cnn* m, const float* d_feat, int n_clips, int height, in
     if (n_clips == 0) return COUGH_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(d_workspace);
-    if (m->esize == 4)
-        return cnn_forward_impl<float>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap);
-    return cnn_forward_impl<bf16_t>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap);
+    const int e = m->esize == 4
+        ? cnn_forward_impl<float>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap)
+        : cnn_forward_impl<bf16_t>(m, d_feat, n_clips, height, width, d_logits, d_probs, d_preds, ws, st, tap_layer, d_tap);
+    if (e == COUGH_OK && d_logits) {   // a NaN pixel -> NaN logits (nn_common.h: torch's ReLU / max-pool propagate it)
+        hipLaunchKernelGGL(nan_rule_kernel, dim3(n_clips), dim3(256), 0, st, d_feat, (long long)height * width, nullptr, d_logits,
+                           d_probs, d_preds);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    return e;
 }
 }  // namespace
 

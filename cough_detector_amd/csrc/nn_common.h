@@ -57,5 +57,37 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
     lo.y = pk_bf16(c - __uint_as_float(hi.y << 16), d - __uint_as_float(hi.y & 0xffff0000u));
 }
 
+// NaN rule of the reference's classifiers.  torch's ReLU and max-pool PROPAGATE NaN (relu(NaN) = NaN, max(NaN, x) = NaN), every
+// convolution mixes all input channels and every input pixel lies under some window of every (strided) conv, and the global
+// average pool sees every position: ONE NaN pixel in a clip's image makes every logit of that clip NaN -- which is what the
+// reference's own default constructor produces (6 contrast bands -> NaN rows, /root/reference/src/preprocessing.py:272-300), so
+// its engine never fires on such a configuration.  ReLU and pooling here are v_max_f32, which returns the non-NaN operand;
+// instead of paying a compare + select at every ReLU, the rule is applied where it ends up: this kernel runs after the head, one
+// workgroup per clip, takes the verdict of the stem's staging loop (flag) or scans the image itself (flag == nullptr), and
+// overwrites the clip's logits / probabilities with NaN (argmax of two NaNs: index 0, as torch.argmax).
+__global__ __launch_bounds__(256) void nan_rule_kernel(const float* __restrict__ x, long long per_clip, const int* __restrict__ flag,
+                                                       float* __restrict__ logits, float* __restrict__ probs,
+                                                       int* __restrict__ preds) {
+    const long long clip = blockIdx.x;
+    int bad = 0;
+    if (flag) {
+        bad = flag[clip];
+    } else {
+        const float* p = x + clip * per_clip;
+        for (long long i = threadIdx.x; i < per_clip; i += 256) bad |= (p[i] != p[i]) ? 1 : 0;
+        bad = __syncthreads_or(bad);
+    }
+    if (bad && threadIdx.x == 0) {
+        const float nan = __builtin_nanf("");
+        logits[clip * 2] = nan;
+        logits[clip * 2 + 1] = nan;
+        if (probs) {
+            probs[clip * 2] = nan;
+            probs[clip * 2 + 1] = nan;
+        }
+        if (preds) preds[clip] = 0;
+    }
+}
+
 }  // namespace
 }  // namespace cough

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
                                                         int nrows, int pitch,
                                                         const bf16_t* __restrict__ wfrag /* [X3 ? 2 : 1][4][2][32][8] */,
                                                         const float* __restrict__ bias,
-                                                        std::conditional_t<X3, float, bf16_t>* __restrict__ out) {
+                                                        std::conditional_t<X3, float, bf16_t>* __restrict__ out,
+                                                        int* __restrict__ nanflag /* [clips]: 1 = the image holds a NaN (nan_rule_kernel) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);
     constexpr int NP = X3 ? 2 : 1;
@@ -164,7 +165,11 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     }
     for (int i = tid; i < NP * plane / 8; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
     for (int i = (NP * plane / 8) * 8 + tid; i < NP * plane; i += 256) img[i] = 0;
-    __syncthreads();
+    int bad = 0;
+#pragma unroll
+    for (int u = 0; u < SB_MAXL; ++u) bad |= (pv[u].x != pv[u].x || pv[u].y != pv[u].y) ? 1 : 0;
+    bad = __syncthreads_or(bad);
+    if (tid == 0) nanflag[clip] = bad;
     const float inv_w = 1.0f / float(W);
 #pragma unroll
     for (int u = 0; u < SB_MAXL; ++u) {
@@ -866,11 +871,14 @@ int upload_packed(cough_resnet* m, int slot, const FoldedConv& main, const Folde
 
 struct Workspace {
     char *a1, *h0, *a2, *h1, *a3;
+    int* nanflag;
     size_t total;
 };
 Workspace carve(const cough_resnet* m, char* base, int n, const Shapes& s) {
     Workspace w;
     size_t off = 0;
+    w.nanflag = reinterpret_cast<int*>(base);   // one int per clip (nan_rule_kernel)
+    off += align256(size_t(n) * sizeof(int));
     auto take = [&](size_t elems) { char* p = base + off; off += align256(elems * m->esize); return p; };
     w.a1 = take(size_t(n) * s.P1h * s.P1w * 32);
     w.h0 = take(size_t(n) * s.B0h * s.B0w * 64);
@@ -948,6 +956,8 @@ int gen_forward(const cough_resnet_generic* g, const float* d_feat, int n, int H
     hipLaunchKernelGGL(tail_generic_kernel, dim3(n), dim3(128), 0, st, w.a[L], sh[L].h * sh[L].w, g->ch[L], g->chp[L],
                        g->d_fcw, g->d_fcb, d_logits, d_probs, d_preds);
     COUGH_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nan_rule_kernel, dim3(n), dim3(256), 0, st, d_feat, (long long)H * W, nullptr, d_logits, d_probs, d_preds);
+    COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
 
@@ -1017,19 +1027,22 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                  int* d_preds, char* ws, hipStream_t st, bool stem_done = false) {
     const Workspace w = carve(m, ws, n, s);
     const long long n_pool = (long long)n * s.P1h * s.P1w;
+    const int* nanflag = nullptr;   // set when the stem's staging loop has looked at every pixel (nan_rule_kernel)
     if (stem_done) {
         // a1 was produced by the featurise kernel (cough_pipeline_forward)
     } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * STEM_SB_MAXL) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
             hipLaunchKernelGGL(stem_bf16_kernel<false>, dim3(n), dim3(256), l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
-                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1));
+                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<bf16_t*>(w.a1), w.nanflag);
+            nanflag = w.nanflag;
         }
     } else if (m->dtype == COUGH_DTYPE_BF16X3 && 2 * stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * STEM_SB_MAXL) {
         if constexpr (sizeof(T) == 4) {
             const StemLds l = stem_lds(s);
             hipLaunchKernelGGL(stem_bf16_kernel<true>, dim3(n), dim3(256), 2 * l.bytes, st, d_feat, s.H, s.W, s.P1h, s.P1w,
-                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<float*>(w.a1));
+                               l.nrows, l.pitch, m->d_stem_wfrag, m->d_stem_b, reinterpret_cast<float*>(w.a1), w.nanflag);
+            nanflag = w.nanflag;
         }
     } else {
         const long long tiles = (n_pool + 7) / 8;
@@ -1126,6 +1139,11 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     if (!head_done) {
         hipLaunchKernelGGL(tail_kernel<T>, dim3(n), dim3(128), 0, st, reinterpret_cast<const T*>(w.a3), s.B1h * s.B1w,
                            m->d_fcw, m->d_fcb, d_logits, d_probs, d_preds);
+        COUGH_HIP_CHECK(hipGetLastError());
+    }
+    if (!stem_done) {   // a NaN pixel -> NaN logits, as torch's ReLU / max-pool propagate it (the fused featuriser cannot emit one)
+        hipLaunchKernelGGL(nan_rule_kernel, dim3(n), dim3(256), 0, st, d_feat, (long long)s.H * s.W, nanflag, d_logits, d_probs,
+                           d_preds);
         COUGH_HIP_CHECK(hipGetLastError());
     }
     return COUGH_OK;

@@ -161,3 +161,24 @@ def test_conv_stack_batch_beyond_2_gib_of_activations(kind, dtype):
     x = torch.rand(36000, 1, 90, 101, device="cuda")
     y = m(x)
     assert torch.isfinite(y).all() and torch.equal(y[-300:], m(x[-300:]))
+
+
+@pytest.mark.parametrize("kind", ["standard", "small"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_nan_pixel_gives_nan_logits_as_torch_does(cnn_golden, kind, dtype):
+    """torch's ReLU and max-pool propagate NaN, so one NaN pixel makes that clip's logits NaN in the reference (and only that
+    clip's); v_max_f32 would have dropped it (nn_common.h: nan_rule_kernel)."""
+    sd = cnn_golden[kind][0]
+    m = cda.create_model(kind, n_mels=90, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    x = torch.rand(5, 1, 90, 101, generator=torch.Generator().manual_seed(3))
+    clean = m(x.cuda()).cpu()
+    x[1, 0, 89, 100] = float("nan")
+    x[3, 0, 0, 0] = float("nan")
+    got = m(x.cuda()).cpu()
+    want = ocnn.FORWARD[kind](x, sd)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.isnan(got[[1, 3]]).all()
+    assert torch.equal(got[[0, 2, 4]], clean[[0, 2, 4]])
+    preds, probs = m.predict(x.cuda())
+    assert torch.isnan(probs[[1, 3]]).all() and preds[1].item() == 0 and preds[3].item() == 0

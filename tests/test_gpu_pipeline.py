@@ -108,3 +108,25 @@ def test_pipeline_batch_beyond_2_gib_of_activations(resnet_golden):
     idx = torch.tensor([0, 1, 16383, 16384, 32767, 32768, 33554, 39998, 39999])
     ref = ores.forward(ofeat.extract_features_batch(w[idx].cpu(), normalize_first=True).unsqueeze(1), sd)
     assert (logits[idx].cpu() - ref).abs().max().item() < LOGIT_TOL
+
+
+def test_reference_default_constructor_gives_nan_logits_as_the_reference_does(resnet_heights_golden):
+    """AudioPreprocessor() with every default (6 contrast bands): the reference's contrast rows are NaN by construction
+    (/root/reference/src/preprocessing.py:272-300), its ReLU / max-pool propagate the NaN, and every logit is NaN -- its engine
+    never fires in that configuration.  Same here, on the pipeline and on model(features)."""
+    import warnings
+    sd, _ = resnet_heights_golden["h110"]
+    w = synth_batch(300, 6, peak_normalize=False) * 0.5
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pre = cda.AudioPreprocessor(device="cuda")
+        model = cda.create_model("residual", n_mels=110, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+        model.load_state_dict(sd)
+        pipe = cda.CoughPipeline(pre, model.cuda())
+        logits, feats = pipe(w.cuda(), normalize=True, return_features=True)
+        ref = ores.forward(ofeat.extract_features_batch(w, normalize_first=True, use_pre_emphasis=True, use_delta_delta=True,
+                                                        use_pcen=True, use_spectral_contrast=True, n_contrast_bands=6).unsqueeze(1), sd)
+        preds, probs = pipe.predict(w.cuda(), normalize=True)
+    assert feats.shape == (6, 110, 101) and torch.isnan(feats[:, 103:]).all() and torch.isfinite(feats[:, :103]).all()
+    assert torch.isnan(ref).all() and torch.isnan(logits).all() and torch.isnan(model(feats.unsqueeze(1))).all()
+    assert torch.isnan(probs).all() and int(preds.abs().sum()) == 0
