@@ -38,6 +38,15 @@ def _cuda_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _check_waveform(w, who: str) -> None:
+    """torch.stft (the reference's T.Spectrogram) takes floating-point TENSORS only; an integer tensor (raw int16 PCM) would be
+    featurised at 32768 times the amplitude, silently -- refuse it as the reference does."""
+    if not isinstance(w, torch.Tensor):
+        raise TypeError(f"{who}: expected a torch.Tensor, got {type(w).__name__}")
+    if not w.dtype.is_floating_point:
+        raise TypeError(f"{who}: expected a floating-point waveform, got {w.dtype} (scale integer PCM to [-1, 1] first)")
+
+
 class AudioPreprocessor:
     """waveform -> stacked (mel | MFCC | delta [| delta-delta]) feature image on the GPU."""
 
@@ -303,6 +312,7 @@ class AudioPreprocessor:
         """(B, N) float32 on the GPU -> (B, F, 1 + N // hop_length) float32 on the GPU (stream-ordered, no host sync);
         N = ``segment_samples`` is the tuned path, any other length runs on the generic kernel chain with a handle
         cached per length.  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
+        _check_waveform(waveforms, "featurize_batch")
         if waveforms.dim() != 2 or waveforms.shape[1] < 1:
             raise ValueError(f"featurize_batch: expected (B, N), got {tuple(waveforms.shape)}")
         n_samples = waveforms.shape[1]
@@ -363,6 +373,7 @@ class AudioPreprocessor:
 
     def extract_features(self, waveform: torch.Tensor) -> torch.Tensor:
         """(1, N) -> (1, F, T) like the reference; also (B, N) / (B, 1, N) -> (B, F, T)."""
+        _check_waveform(waveform, "extract_features")
         if waveform.dim() == 3:
             if waveform.shape[1] != 1:
                 raise ValueError("extract_features: (B, C, N) input needs C == 1")

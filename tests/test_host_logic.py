@@ -295,3 +295,12 @@ def test_effective_dtype_reports_the_kernels_that_run():
     assert cda.create_model("residual", compute_dtype="bf16_approx").effective_dtype() == "bf16_approx"
     with pytest.warns(UserWarning, match="APPROXIMATE single-bf16 mode"):      # the old name still works, loudly
         assert cda.create_model("residual", compute_dtype="bf16").compute_dtype == "bf16_approx"
+
+
+def test_featuriser_refuses_non_tensor_and_integer_waveforms():
+    import numpy as np
+    pre = cda.AudioPreprocessor(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+    with pytest.raises(TypeError, match="torch.Tensor"):
+        pre.extract_features(np.zeros((1, 16000), np.float32))
+    with pytest.raises(TypeError, match="floating-point"):
+        pre.extract_features(torch.zeros(1, 16000, dtype=torch.int16))     # torch.stft refuses integer input as well
