@@ -1,7 +1,7 @@
 """The W > 1 RCCL exchange on real hardware -- runs by itself whenever `pytest -m gpu` lands on a node with >= 2 GPUs.
 
-Skipped on a one-GPU box.  Otherwise a FRESH CHILD process (`python -m torch.distributed.run --nproc-per-node <all
-visible GPUs>` on tests/multirank_check.py; a child, never an exec of this pytest process, which has initialised the
+Skipped on a one-GPU box.  Otherwise a FRESH CHILD process (`python -m torch.distributed.run --nproc-per-node <visible
+GPUs, at most 4>` on tests/multirank_check.py; a child, never an exec of this pytest process, which has initialised the
 GPU) scores three ragged streams with one rank per GPU -- ragged buckets, send-buffer reuse and the end-of-stream flush
 on RCCL over xGMI -- and must exit 0: gathered logits bit-identical to the single-rank ones on every rank and within
 the logit tolerance of the CPU oracle at 64 sampled global indices.  SURVEY.md 8e, BASELINE.json configs[3]."""
@@ -27,7 +27,9 @@ def test_all_visible_gpus_rccl_exchange_in_a_fresh_child():
     n = torch.cuda.device_count()
     if n < 2:
         pytest.skip(f"{n} GPU visible: the W > 1 RCCL exchange needs >= 2 (it runs by itself on a multi-GPU node)")
-    n = min(n, 8)
+    # at most 4 ranks by default: with this pytest process that is 5 processes holding a GPU, inside the 6 a shared box allows a
+    # job; COUGH_TEST_MAX_RANKS=8 widens it on a node of one's own
+    n = min(n, int(os.environ.get("COUGH_TEST_MAX_RANKS", "4")))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
