@@ -329,7 +329,7 @@ template <bool MAG, bool MEL>
 __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
                                                            int nfft, const float* __restrict__ win /* [nfft] */, GenDft tab,
                                                            const float* __restrict__ peaks, int pre_emph, float coef,
-                                                           float* __restrict__ out, GenMel mel) {
+                                                           float* __restrict__ out, GenMel mel, long long n_rows /* clips x T */) {
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int nfreq = nfft / 2 + 1, pad = nfft / 2, nh = nfft / 2;   // n = 0 .. nh
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,8 +337,12 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
     float* sp = reinterpret_cast<float*>(smem_d);       // [KC][32] sums of the current chunk
     float* df = sp + G_DFT_KC * G_DFT_M;                // [KC][32] differences
     float* spec = df + G_DFT_KC * G_DFT_M;              // [32][pitch + 1]
-    const long long clip = blockIdx.y;
-    const int t0 = blockIdx.x * G_DFT_M;
+    // the 32 rows of a workgroup are 32 consecutive (clip, frame) pairs of the launch: no padding of T to whole tiles, a tile may
+    // straddle two clips.  A thread stages the same row f = tid % 32 throughout.
+    const long long row = (long long)blockIdx.x * G_DFT_M + (tid & 31);
+    const bool row_live = row < n_rows;
+    const long long clip = row_live ? row / T : (n_rows - 1) / T;
+    const int t = row_live ? int(row - clip * T) : T - 1;
     const float* x = wav + clip * stride;
     const float m = peaks ? peaks[clip] : 0.f;
     const float inv_m = m > 0.f ? 1.0f / m : 1.0f;
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
         if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));
         return v;
     };
+    const int s0f = hop * t - pad;
     const int col = lane & 31, half = lane >> 5;
     for (int pass0 = 0; pass0 < n_tiles; pass0 += 8) {
         const int tile_a = pass0 + wave, tile_b = pass0 + 4 + wave;   // wave-uniform
@@ -369,23 +374,23 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
         for (int n0 = 0; n0 <= nh; n0 += G_DFT_KC) {
             __syncthreads();   // the previous chunk has been consumed
             for (int i = tid; i < G_DFT_KC * G_DFT_M; i += 256) {
-                const int n = n0 + (i >> 5), f = i & 31;
+                const int n = n0 + (i >> 5);   // i % 32 == tid % 32: this thread's row
                 float a = 0.f, b = 0.f;
                 bool paired = false;
                 if (n <= nh) {
-                    const int t = t0 + f < T ? t0 + f : T - 1;
-                    const int s0 = hop * t - pad, n2 = nfft - n;
-                    a = value(s0 + n) * win[n];
+                    const int n2 = nfft - n;
+                    a = value(s0f + n) * win[n];
                     paired = n > 0 && n2 != n;
-                    if (paired) b = value(s0 + n2) * win[n2];
+                    if (paired) b = value(s0f + n2) * win[n2];
                 }
                 sp[i] = a + b;
                 df[i] = paired ? a - b : 0.f;
             }
             __syncthreads();
             if (has_a) {
+                const int gn = tab.groups - (n0 >> 3) < G_DFT_KC / 8 ? tab.groups - (n0 >> 3) : G_DFT_KC / 8;   // groups of 8 n left
 #pragma unroll 2
-                for (int gi = 0; gi < G_DFT_KC / 8; ++gi) {
+                for (int gi = 0; gi < gn; ++gi) {
                     const int g = (n0 >> 3) + gi;
                     const float4 ca = nca, sa = nsa, cb = ncb, sb = nsb;
                     if (g + 1 < tab.groups) load_b(g + 1);   // the next group's fragments fly while this one is multiplied
@@ -435,23 +440,22 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
         }
     }
     __syncthreads();
+    // frame-major stores: thread = (row f = tid % 32, bin / band i / 32); a row's clip and frame are this thread's own
     if constexpr (MEL) {
-        float* o = out + clip * (long long)mel.n_mels * T;
-        for (int i = tid; i < mel.n_mels * G_DFT_M; i += 256) {
-            const int mb = i >> 5, f = i & 31;
+        float* o = out + clip * (long long)mel.n_mels * T + t;
+        const float* srow = spec + (tid & 31) * SP;
+        for (int mb = tid >> 5; mb < mel.n_mels; mb += 8) {
             const int l = mel.lo[mb], hb = mel.hi[mb];
             const float* wm = mel.w + mel.off[mb];
-            const float* row = spec + f * SP;
             float acc = 0.f;
-            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], row[k], acc);
-            if (t0 + f < T) o[(long long)mb * T + t0 + f] = acc;
+            for (int k = l; k < hb; ++k) acc = fmaf(wm[k - l], srow[k], acc);
+            if (row_live) o[(long long)mb * T] = acc;
         }
     } else {
-        float* o = out + clip * (long long)nfreq * T;
-        for (int i = tid; i < nfreq * G_DFT_M; i += 256) {
-            const int k = i >> 5, f = i & 31;
-            if (t0 + f < T) o[(long long)k * T + t0 + f] = spec[f * SP + k];
-        }
+        float* o = out + clip * (long long)nfreq * T + t;
+        const float* srow = spec + (tid & 31) * SP;
+        for (int k = tid >> 5; k < nfreq; k += 8)
+            if (row_live) o[(long long)k * T] = srow[k];
     }
 }
 
@@ -695,9 +699,10 @@ void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
     } else {
-        hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((g->T + G_DFT_M - 1) / G_DFT_M, nc), dim3(256),
+        const long long n_rows = (long long)nc * g->T;
+        hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_DFT_M - 1) / G_DFT_M)), dim3(256),
                            dft_lds_bytes(g->dft.pitch), stream, w, wav_stride, g->N, g->hop, g->T, g->nfft, win, g->dft, peaks, pre_emph,
-                           coef, out, mel);
+                           coef, out, mel, n_rows);
     }
 }
 }  // namespace
@@ -733,7 +738,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     // gen_stft_dft_kernel's matrices (n_fft not a power of two): [n rounded up to the chunk][bins rounded up to 32], zero padded
     const bool use_dft = !(nfft >= 64 && (nfft & (nfft - 1)) == 0);
     const int dft_pitch = use_dft ? (nfreq + 31) / 32 * 32 : 0;
-    const int dft_rows = use_dft ? (nfft / 2 + 1 + G_DFT_KC - 1) / G_DFT_KC * G_DFT_KC : 0;
+    const int dft_rows = use_dft ? (nfft / 2 + 1 + 7) / 8 * 8 : 0;   // n padded to whole groups of 8 (zero rows)
     std::vector<float> dft_cos(size_t(dft_rows) * dft_pitch, 0.f), dft_sin(size_t(dft_rows) * dft_pitch, 0.f);
     if (use_dft) {
         std::vector<double> cd(nfft), sd(nfft);
