@@ -81,13 +81,17 @@ template <bool MAG, bool MEL>
 __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
                                                        const float2* __restrict__ tw512, const float* __restrict__ peaks,
-                                                       int pre_emph, float coef, float* __restrict__ out, GenMel mel) {
+                                                       int pre_emph, float coef, float* __restrict__ out, GenMel mel,
+                                                       long long n_rows /* clips x T */) {
     __shared__ float xs[4 * 4 * G_XFRAME];
     __shared__ float otile[G_NFREQ * (G_FPB + 1)];
     __shared__ float2 twl[16 * G_XROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, fsub = lane >> 4;
-    const long long clip = blockIdx.y;
-    const int f16 = wave * 4 + fsub, t_raw = blockIdx.x * G_FPB + f16, t = t_raw < T ? t_raw : T - 1;
+    // the 16 frames of a workgroup are 16 consecutive (clip, frame) pairs of the launch: T is not padded to whole tiles
+    const int f16 = wave * 4 + fsub;
+    const long long row0 = (long long)blockIdx.x * G_FPB, row = row0 + f16 < n_rows ? row0 + f16 : n_rows - 1;
+    const long long clip = row / T;
+    const int t = int(row - clip * T);
     twl[(tid >> 4) * G_XROW + (tid & 15)] = tw256[tid];
     __syncthreads();
     const float2* tw_row = twl + j * G_XROW;
@@ -170,8 +174,11 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
             meta[2 * G_MAX_MELS + i] = mel.off[i];
         }
         __syncthreads();
-        const int f = tid & 15, tt = blockIdx.x * G_FPB + f;
-        float* o = out + clip * (long long)mel.n_mels * T;
+        const int f = tid & 15;                         // the output row of this thread: its own (clip, frame)
+        const long long orow = row0 + f;
+        const bool live = orow < n_rows;
+        const long long oclip = live ? orow / T : 0;
+        float* o = out + oclip * (long long)mel.n_mels * T + (orow - oclip * T);
         auto project = [&](const float* wbase) {
             for (int m = tid >> 4; m < mel.n_mels; m += 16) {
                 const int l = meta[m], hb = meta[G_MAX_MELS + m];
@@ -180,17 +187,19 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
                 float acc = 0.f;
 #pragma unroll 4
                 for (int k = l; k < hb; ++k) acc = fmaf(wm[k], col[k * (G_FPB + 1)], acc);
-                if (tt < T) o[(long long)m * T + tt] = acc;
+                if (live) o[(long long)m * T] = acc;
             }
         };
         if (staged) project(wl);
         else project(mel.w);
     } else {
-        float* o = out + clip * (long long)G_NFREQ * T;
-        for (int idx = tid; idx < G_NFREQ * G_FPB; idx += 256) {
-            const int k = idx >> 4, f = idx & 15, tt = blockIdx.x * G_FPB + f;
-            if (tt < T) o[(long long)k * T + tt] = otile[k * (G_FPB + 1) + f];
-        }
+        const int f = tid & 15;                         // idx % 16 == tid % 16: one output row per thread
+        const long long orow = row0 + f;
+        const bool live = orow < n_rows;
+        const long long oclip = live ? orow / T : 0;
+        float* o = out + oclip * (long long)G_NFREQ * T + (orow - oclip * T);
+        for (int k = tid >> 4; k < G_NFREQ; k += 16)
+            if (live) o[(long long)k * T] = otile[k * (G_FPB + 1) + f];
     }
 }
 
@@ -693,8 +702,9 @@ template <bool MAG, bool MEL>
 void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int nc, const float* win, const float* peaks,
                      int pre_emph, float coef, float* out, const GenMel& mel, hipStream_t stream) {
     if (g->nfft == G_NFFT) {
-        hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((g->T + G_FPB - 1) / G_FPB, nc), dim3(256), 0, stream, w, wav_stride,
-                           g->N, g->hop, g->T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel);
+        const long long n_rows = (long long)nc * g->T;
+        hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_FPB - 1) / G_FPB)), dim3(256), 0, stream, w,
+                           wav_stride, g->N, g->hop, g->T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows);
     } else if (g->nfft >= 64 && (g->nfft & (g->nfft - 1)) == 0) {
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
