@@ -218,6 +218,7 @@ def test_extract_features_takes_a_waveform_of_any_length_like_the_reference():
 
 @pytest.mark.parametrize("n_fft,flags", [(400, dict(use_pre_emphasis=True, use_spectral_contrast=True, n_contrast_bands=3)),
                                          (301, dict(use_delta_delta=True, use_pcen=True)), (1000, dict()), (32, dict(use_mfcc=False)),
+                                         (2000, dict(use_pre_emphasis=True)),       # 1001 bins: 32 bin tiles in 4 passes, 147 KB of LDS
                                          (1024, dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)),
                                          (1024, dict(use_spectral_contrast=True, n_contrast_bands=4)),
                                          (256, dict(use_spectral_contrast=True, n_contrast_bands=3, use_pre_emphasis=True)),
