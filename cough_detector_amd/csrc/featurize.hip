@@ -161,12 +161,6 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 
     // ---------------- P1: STFT power -> mel -> dB ----------------
     const int j = lane & 15, fsub = lane >> 4;
-    float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
-#pragma unroll
-    for (int n1 = 1; n1 < 15; ++n1) {
-        w_re[n1] = tb->win[32 * n1 + 2 * j];
-        w_im[n1] = tb->win[32 * n1 + 2 * j + 1];
-    }
     twl[(tid >> 4) * XROW + (tid & 15)] = tb->tw256[tid >> 4][tid & 15];   // 256 threads = 16 x 16 entries
     __syncthreads();
     const float2* tw_row = twl + j * XROW;   // row pitch 17 float2: the 16 lanes of a frame hit 16 distinct banks
@@ -179,6 +173,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     float* myx = xs + (wave * FPW + fsub) * XFRAME;
     float run_max = -INFINITY;   // max raw dB seen by this lane
     float peak = 0.f;            // max |sample| seen by this lane
+    float chk = 0.f;             // stays 0 while every mel power of this lane is finite, NaN otherwise (acc * 0)
     // Frame samples are fetched one group AHEAD of their use (28 VGPRs): the HBM/L2 latency of a
     // group's 14 eight-byte loads hides behind the ~600 VALU instructions of the previous group, and every
     // byte of the clip is requested from HBM once.
@@ -204,6 +199,17 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         }
     };
     float2 raw[16];
+    float peak_m = 0.f;   // block peak of the (possibly rescaled) samples, fused normalise only
+    // P1 as a body that can run twice: once for every clip, and a second time -- window taps scaled by a power of two -- for a
+    // clip whose peak lies outside 2^-50 .. 2^50 under the fused normalise (never audio; see below)
+    auto p1_pass = [&](const float ws1, const float ws2) {
+    float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
+    const int jw = 2 * j;
+#pragma unroll
+    for (int n1 = 1; n1 < 15; ++n1) {
+        w_re[n1] = tb->win[32 * n1 + jw] * ws1 * ws2;
+        w_im[n1] = tb->win[32 * n1 + jw + 1] * ws1 * ws2;
+    }
     load_group(wave, raw);
 
     K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
@@ -317,21 +323,56 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 const float db = 3.01029995663981195f * __log2f(acc);
                 melbuf[lane * NFRAMES + tf] = db;
                 run_max = fmaxf(run_max, db);
+                chk = fmaf(acc, 0.f, chk);   // NaN / Inf power (a non-finite sample under the frame, f32 overflow) -> NaN, sticky
             }
         }
         wave_lds_fence();
     }
 
+    };
+    p1_pass(1.f, 1.f);
+
     K1_MARK("ENDLOOP");
     K1_MARK("PHASE P2 block max / peak, shift and floor");
     K1_STAMP(2);   // wave 0 finished its frames
     // ---------------- P2: top_db floor, mel rows, DCT, z-score, deltas ----------------
-    const float raw_max = block_max(run_max, red, tid);
-    float shift = 0.f;   // 20*log10(peak): waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212)
     if (normalize) {
-        const float m = block_max(peak, red, tid);
-        if (m > 0.f) shift = 20.0f * log10f(m);
+        peak_m = block_max(peak, red, tid);
+        // Peak normalisation is applied as a shift in dB, which needs the power of the RAW samples to be representable: a clip
+        // whose peak lies outside 2^-50 .. 2^50 (never audio) is transformed again with the window taps scaled by a power of
+        // two (exact), so that the reference's `waveform / max` (preprocessing.py:209-212) holds for denormal and huge peaks too
+        const int pe = (__float_as_int(peak_m) >> 23) & 0xff;   // biased exponent: 0 = zero / denormal, 255 = Inf
+        // silence stays as it is; an Inf sample is caught below
+        if ((pe < 127 - 50 || pe > 127 + 50) && peak_m != 0.f && pe != 255) {   // workgroup-uniform
+            const int e = pe ? pe - 127 : -127 - __builtin_clz(__float_as_int(peak_m) << 9);   // floor(log2(peak))
+            const int k = (e > 0 ? 40 : -40) - e;                                                // peak * 2^k ~ 2^+-40
+            const float ws1 = __int_as_float((127 + k / 2) << 23);   // 2^k in two exact factors
+            const float ws2 = __int_as_float((127 + k - k / 2) << 23);
+            peak_m = peak_m * ws1 * ws2;
+            run_max = -INFINITY;
+            chk = 0.f;
+            __syncthreads();   // every wave is through its mel reads before the scratch / dB buffer are written again
+            p1_pass(ws1, ws2);
+        }
     }
+    if (chk != chk) run_max = INFINITY;   // finite powers give a finite or -inf dB: +inf marks the clip
+    const float raw_max = block_max(run_max, red, tid);
+    // A NaN or Inf sample (or an f32 overflow of the power) makes the reference's WHOLE image NaN: the frames over it are NaN in
+    // every bin, AmplitudeToDB's per-clip `amax` is then NaN and its floor poisons every cell, the z-scores and deltas follow
+    // (preprocessing.py:405-410, :428; normalize() leaves a clip with a NaN maximum alone, :209-212)
+    if (raw_max == INFINITY) {   // workgroup-uniform
+        const float nanv = __builtin_nanf("");
+        const int rows = NMEL + (delta_delta == 2 ? 0 : (delta_delta == 1 ? 3 : 2) * NMFCC);
+        if (wr)
+            for (int i = tid; i < rows * NFRAMES; i += THREADS) o[i] = nanv;
+        if constexpr (STEM != 0)
+            if (tid == 0) stem.nanflag[clip] = 1;   // a1 is left unwritten: the head overwrites this clip's logits
+        return;
+    }
+    if constexpr (STEM != 0)
+        if (tid == 0) stem.nanflag[clip] = 0;
+    float shift = 0.f;   // 20*log10(peak): waveform / waveform.abs().max() if max > 0 (preprocessing.py:209-212)
+    if (normalize && peak_m > 0.f) shift = 20.0f * log10f(peak_m);
     // AmplitudeToDB('power', top_db=80): amin = 1e-10 <=> -100 dB; the floor is relative to the per-clip max
     const float floor_db = fmaxf(raw_max - shift, -100.0f) - 80.0f;
     K1_STAMP(3);   // all waves finished P1
@@ -732,7 +773,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
     const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
-    const StemFuse none{nullptr, nullptr, nullptr, 0};
+    const StemFuse none{nullptr, nullptr, nullptr, 0, nullptr};
     if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);

@@ -62,10 +62,31 @@ __global__ __launch_bounds__(256) void gen_peak_kernel(const float* __restrict__
     __shared__ float red[4];
     const float* x = wav + blockIdx.x * stride;
     float m = 0.f;
-    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, fabsf(x[i]));
+    int isnan = 0;   // torch's max propagates NaN (`waveform.abs().max()`, :209): the clip is then left unscaled (NaN > 0 is False)
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = x[i];
+        m = fmaxf(m, fabsf(v));
+        isnan |= v != v;
+    }
     m = g_block_max(m, red, threadIdx.x);
-    if (threadIdx.x == 0) peaks[blockIdx.x] = m;
+    isnan = __syncthreads_or(isnan);
+    if (threadIdx.x == 0) peaks[blockIdx.x] = isnan ? __builtin_nanf("") : m;
 }
+
+// x / peak of normalize() (:209-212) as x * (1 / peak) -- within 1 ulp, a third of the STFT kernels' VALU cheaper -- for every
+// peak whose reciprocal is a normal number; a denormal peak (1 / peak overflows) and an infinite one (x / inf = 0, inf / inf =
+// NaN) take the true division.  A NaN peak (a NaN sample) and a zero one leave the clip unscaled.
+struct PeakScale {
+    float m, inv;
+    bool div;
+    __device__ __forceinline__ explicit PeakScale(float peak) {
+        const bool norm = peak > 0.f;            // False for NaN
+        div = norm && !(peak >= 1.2e-38f && peak <= 3.0e38f);
+        m = peak;
+        inv = norm && !div ? 1.0f / peak : 1.0f;
+    }
+    __device__ __forceinline__ float operator()(float x) const { return div ? x / m : x * inv; }
+};
 
 // ------------------------------------------------------------------------------------------------ STFT
 // One workgroup = 16 consecutive frames of one clip; 16 lanes per frame, as in featurize.hip / spectrogram.hip.
@@ -97,10 +118,8 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     const float2* tw_row = twl + j * G_XROW;
     const float2 tw_j = tw512[j];
     const float* x = wav + clip * stride;
-    const float m = peaks ? peaks[clip] : 0.f;
-    const bool norm = m > 0.f;   // "if max_val > 0: waveform / max_val" (:209-212)
-    const float inv_m = norm ? 1.0f / m : 1.0f;   // x * (1 / m): within 1 ulp of x / m, a third of this kernel's VALU cheaper
-    auto sample = [&](int i) -> float { return x[i] * inv_m; };
+    const PeakScale scale(peaks ? peaks[clip] : 0.f);   // "if max_val > 0: waveform / max_val" (:209-212)
+    auto sample = [&](int i) -> float { return scale(x[i]); };
     auto value = [&](int i) -> float {   // sample i of the (normalised, pre-emphasised) signal, i already inside the clip
         float v = sample(i);
         if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));   // y[n] = x[n] - coef x[n-1], y[0] = x[0]
@@ -227,9 +246,8 @@ __global__ __launch_bounds__(256) void gen_stft_pow2_kernel(const float* __restr
     const long long clip = blockIdx.y;
     const int t_raw = blockIdx.x * 4 + wave, t = t_raw < T ? t_raw : T - 1;
     const float* x = wav + clip * stride;
-    const float m = peaks ? peaks[clip] : 0.f;
-    const float inv_m = m > 0.f ? 1.0f / m : 1.0f;
-    auto sample = [&](int i) -> float { return x[i] * inv_m; };
+    const PeakScale scale(peaks ? peaks[clip] : 0.f);
+    auto sample = [&](int i) -> float { return scale(x[i]); };
     auto value = [&](int i) -> float {
         i = i < 0 ? -i : (i >= N ? 2 * (N - 1) - i : i);          // reflect padding (N > n_fft / 2: one reflection suffices)
         float v = sample(i);
@@ -353,9 +371,8 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
     const long long clip = row_live ? row / T : (n_rows - 1) / T;
     const int t = row_live ? int(row - clip * T) : T - 1;
     const float* x = wav + clip * stride;
-    const float m = peaks ? peaks[clip] : 0.f;
-    const float inv_m = m > 0.f ? 1.0f / m : 1.0f;
-    auto sample = [&](int i) -> float { return x[i] * inv_m; };
+    const PeakScale scale(peaks ? peaks[clip] : 0.f);
+    auto sample = [&](int i) -> float { return scale(x[i]); };
     auto value = [&](int i) -> float {
         i = i < 0 ? -i : (i >= N ? 2 * (N - 1) - i : i);
         float v = sample(i);
@@ -482,7 +499,10 @@ __device__ __forceinline__ float g_pcen(const float* __restrict__ row, int t, in
     return sqrtf(row[t] / powf(1e-6f + sm / 10.0f, 0.98f) + 2.0f) - 1.41421356237309515f;
 }
 
-// per clip: stat[clip] = {max dB, PCEN min, PCEN max}
+// per clip: stat[clip] = {max dB, PCEN min, PCEN max, poison}.  poison = 0, or NaN for a clip with a non-finite mel power -- a NaN /
+// Inf sample under a frame, an f32 overflow of the power: the reference's dense `spec @ fb` turns an Inf bin into NaN bands
+// (0 * inf), AmplitudeToDB's per-clip amax is then NaN and its floor makes EVERY cell of the clip NaN (:405-410), PCEN's min /
+// max likewise (:402-404), the MFCC z-score and the deltas follow (:428); gen_rows_kernel adds the poison to what it writes
 __global__ __launch_bounds__(256) void gen_dbstat_kernel(const float* __restrict__ melpow, int T, int n_mels, int pcen,
                                                          float* __restrict__ stat) {
     __shared__ float red[4];
@@ -491,7 +511,9 @@ __global__ __launch_bounds__(256) void gen_dbstat_kernel(const float* __restrict
     const float* mp = melpow + clip * (long long)n_mels * T;
     const long long n = (long long)n_mels * T;
     float mx = -INFINITY, pmin = INFINITY, pmax = -INFINITY;
+    int bad = 0;
     for (long long i = tid; i < n; i += 256) {
+        bad |= !(mp[i] < INFINITY);
         mx = fmaxf(mx, g_db(mp[i]));
         if (pcen) {
             const int m = int(i / T), t = int(i - (long long)m * T);
@@ -503,7 +525,11 @@ __global__ __launch_bounds__(256) void gen_dbstat_kernel(const float* __restrict
     mx = g_block_max(mx, red, tid);
     pmin = -g_block_max(-pmin, red, tid);
     pmax = g_block_max(pmax, red, tid);
-    if (tid == 0) { stat[clip * 4] = mx; stat[clip * 4 + 1] = pmin; stat[clip * 4 + 2] = pmax; }
+    bad = __syncthreads_or(bad);
+    if (tid == 0) {
+        stat[clip * 4] = mx; stat[clip * 4 + 1] = pmin; stat[clip * 4 + 2] = pmax;
+        stat[clip * 4 + 3] = bad ? __builtin_nanf("") : 0.f;
+    }
 }
 
 // mel rows + raw MFCC rows of 64 frames of one clip
@@ -519,14 +545,15 @@ __global__ __launch_bounds__(256) void gen_rows_kernel(const float* __restrict__
     float* o = feat + clip * (long long)nfeat * T;
     const float floor_db = stat[clip * 4] - 80.0f;   // top_db = 80 below the clip's maximum
     const float pmin = stat[clip * 4 + 1], prange = stat[clip * 4 + 2] - pmin + 1e-8f;
+    const float poison = stat[clip * 4 + 3];   // 0, or NaN: a clip with a non-finite mel power is NaN in every cell
     for (int m = wave; m < n_mels; m += 4) {
         float d = 0.f;
         if (t < T) {
-            d = fmaxf(g_db(mp[(long long)m * T + t]), floor_db);
+            d = fmaxf(g_db(mp[(long long)m * T + t]), floor_db) + poison;
             float v;
             if (pcen) v = (g_pcen(mp + (long long)m * T, t, T) - pmin) / prange;          // :402-404
             else v = fminf(fmaxf((d + 80.0f) / 80.0f, 0.f), 1.f);                         // :409-410
-            o[(long long)m * T + t] = v;
+            o[(long long)m * T + t] = v + poison;
         }
         dbt[m * G_TT + lane] = d;
     }

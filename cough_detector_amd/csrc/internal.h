@@ -16,6 +16,7 @@ struct StemFuse {
     const float* bias;       // [32]
     void* a1;                // [n][22][25][32] NHWC: bf16 (x3 == 0) or f32 (x3 == 1)
     int x3;                  // 1: split-bf16 operands (feature image and weights as hi + lo, three MFMAs per k-step)
+    int* nanflag;            // [n]: 1 = the clip holds a non-finite sample -- the reference's image, and so its logits, are NaN
 };
 
 // featurize.hip: d_feat may be nullptr when `stem` is given (features not materialised)

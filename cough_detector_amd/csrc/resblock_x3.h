@@ -62,6 +62,7 @@ struct RbxArgs {
     float* logits;        // [B][2]
     float* probs;         // [B][2] or nullptr
     int* preds;           // [B] or nullptr
+    const int* nanflag;   // fused head: [B] or nullptr; 1 = the clip's image holds a NaN -> NaN logits (nn_common.h: NaN rule)
 };
 
 template <int CIN, int COUT, int G, int XH, int XW>
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 l0 = hred[w0 * 2] + hred[(w0 + 1) * 2] + fb0;
                 l1 = hred[w0 * 2 + 1] + hred[(w0 + 1) * 2 + 1] + fb1;
                 const long long b = clip0 + g;
+                if (a.nanflag != nullptr && a.nanflag[b]) l0 = l1 = __builtin_nanf("");   // probs NaN, argmax 0 as torch.argmax
                 a.logits[b * 2] = l0;
                 a.logits[b * 2 + 1] = l1;
                 if (a.probs) {

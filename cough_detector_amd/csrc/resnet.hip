@@ -1029,7 +1029,8 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     const long long n_pool = (long long)n * s.P1h * s.P1w;
     const int* nanflag = nullptr;   // set when the stem's staging loop has looked at every pixel (nan_rule_kernel)
     if (stem_done) {
-        // a1 was produced by the featurise kernel (cough_pipeline_forward)
+        // a1 was produced by the featurise kernel (cough_pipeline_forward), which also left its verdict on the clip's samples
+        nanflag = w.nanflag;
     } else if (m->dtype == COUGH_DTYPE_BF16 && stem_lds(s).bytes <= 64 * 1024 && s.H * s.W <= 2 * 256 * STEM_SB_MAXL) {
         if constexpr (sizeof(T) == 2) {
             const StemLds l = stem_lds(s);
@@ -1057,6 +1058,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
     const Blk blk[2] = {{w.a1, w.h0, w.a2, s.P1h, s.P1w, s.B0h, s.B0w, 32, 64, 0, 1},
                         {w.a2, w.h1, w.a3, s.B0h, s.B0w, s.B1h, s.B1w, 64, 128, 2, 3}};
     bool head_done = false;   // the fused block-1 kernel also runs the head
+    bool rule_done = false;   // ... and applied the NaN rule from the per-clip flag
     for (int i = 0; i < 2; ++i) {
         const Blk& k = blk[i];
         if constexpr (sizeof(T) == 4) {
@@ -1076,6 +1078,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                     ra.fcw = m->d_fcw; ra.fcb = m->d_fcb; ra.logits = d_logits; ra.probs = d_probs; ra.preds = d_preds;
                     if (stem_done) ra.out = nullptr;   // pipeline: nobody reads a3
                     head_done = true;
+                    if (nanflag) { ra.nanflag = nanflag; rule_done = true; }
                 }
 #define RBX_GO0(R) if (i == 0 && k.xh == R) rbx_launch<32, 64, 1, R, 25>(n, st, ra);
 #define RBX_GO1(R) if (i == 1 && k.xh == R) rbx_launch<64, 128, rbx_block1_clips(R), R, 13>(n, st, ra);
@@ -1141,7 +1144,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
                            m->d_fcw, m->d_fcb, d_logits, d_probs, d_preds);
         COUGH_HIP_CHECK(hipGetLastError());
     }
-    if (!stem_done) {   // a NaN pixel -> NaN logits, as torch's ReLU / max-pool propagate it (the fused featuriser cannot emit one)
+    if (!rule_done) {   // a NaN pixel (pipeline: a non-finite sample) -> NaN logits, as torch's ReLU / max-pool propagate it
         hipLaunchKernelGGL(nan_rule_kernel, dim3(n), dim3(256), 0, st, d_feat, (long long)s.H * s.W, nanflag, d_logits, d_probs,
                            d_preds);
         COUGH_HIP_CHECK(hipGetLastError());
@@ -1450,7 +1453,7 @@ extern "C" int cough_pipeline_forward(const cough_featurizer* f, const cough_res
     if (ev_featurize_begin) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_begin), st));
     if (can_fuse_stem(f, m)) {
         const Workspace w = carve(m, ws, n_clips, s);
-        const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, w.a1, m->dtype == COUGH_DTYPE_BF16X3 ? 1 : 0};
+        const StemFuse stem{m->d_stem_wfrag, m->d_stem_b, w.a1, m->dtype == COUGH_DTYPE_BF16X3 ? 1 : 0, w.nanflag};
         if (int e = launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, &stem, st)) return e;
         if (ev_featurize_end) COUGH_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_featurize_end), st));
         if (m->esize == 4) return forward_impl<float>(m, nullptr, n_clips, s, d_logits, d_probs, d_preds, ws, st, true);

@@ -154,15 +154,20 @@ __global__ __launch_bounds__(1024) void prepare_clip_kernel(const float* __restr
         return C == 1 ? s : s / fc;
     };
     float peak = 0.f;
+    int isnan = 0;   // `waveform.abs().max()` of a signal holding a NaN is NaN, and `NaN > 0` leaves the signal unscaled (:209-212)
     if (normalize) {
-        for (int i = tid; i < n; i += blockDim.x) peak = fmaxf(peak, fabsf(mono(i)));
+        for (int i = tid; i < n; i += blockDim.x) {
+            const float v = mono(i);
+            peak = fmaxf(peak, fabsf(v));
+            isnan |= v != v;
+        }
         peak = wave_max(peak);
         if ((tid & 63) == 0) red[tid >> 6] = peak;
-        __syncthreads();
+        isnan = __syncthreads_or(isnan);
         peak = red[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) peak = fmaxf(peak, red[w]);
     }
-    const bool scale = normalize && peak > 0.f;   // all-zero input: unchanged (preprocessing.py:209-212)
+    const bool scale = normalize && peak > 0.f && !isnan;   // all-zero input: unchanged (preprocessing.py:209-212)
     // n > out_len: window [start, start + out_len), start = (n - out_len) / 2; n < out_len: left = (out_len - n) / 2
     const int shift = n >= out_len ? (n - out_len) / 2 : -((out_len - n) / 2);
     for (int o = tid; o < out_len; o += blockDim.x) {
