@@ -86,34 +86,88 @@ LIVE_PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES"
 LIVE_PMC_KERNELS = ("featurize_kernel", "stft3_kernel", "resblock_x3_kernel<32", "resblock_x3_kernel<64")
 
 
+def under_profiler(env=None) -> bool:
+    """True when this process already runs under rocprofv3 / a rocprofiler tool library: the profiler's preloaded library has
+    initialised the GPU before main(), and everything it exported (LD_PRELOAD, ROCP_TOOL_LIBRARIES, ROCPROF_*) would be
+    inherited by a child."""
+    env = os.environ if env is None else env
+    if any("rocprof" in env.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return True
+    return any(k.startswith("ROCPROF_") or k.startswith("ROCPROFILER_") for k in env)
+
+
+def clean_child_env(env=None) -> dict:
+    """The environment of a child run: this process's, minus everything a profiler exports (so that a nested `rocprofv3`
+    starts from a clean slate) and minus the torchrun variables."""
+    env = dict(os.environ if env is None else env)
+    for k in list(env):
+        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "WORLD_SIZE", "RANK", "LOCAL_RANK") or k.startswith(("ROCP_", "ROCPROF_", "ROCPROFILER_")):
+            del env[k]
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
+def run_child(cmd, env, timeout_s: float, stderr_path: str) -> str:
+    """Run one child to completion.  Returns "" on success, else the reason.  On a time-out the child gets SIGTERM and a grace
+    period before SIGKILL: `rocprofv3` exec's into the profiled program, so the signal lands on a process that is mid-kernel
+    under counter collection."""
+    with open(stderr_path, "wb") as err:
+        try:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=err)
+        except OSError as exc:
+            return f"could not start {cmd[0]}: {exc}"
+        try:
+            rc = proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.terminate()
+            try:
+                proc.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                proc.wait()
+            return f"timed out after {timeout_s:.0f} s"
+    if rc != 0:
+        try:
+            with open(stderr_path, "rb") as f:
+                tail = f.read()[-300:].decode("utf-8", "replace").strip().replace("\n", " | ")
+        except OSError:
+            tail = ""
+        return f"exit code {rc}: {tail}"
+    return ""
+
+
 def live_pmc(args, passes=LIVE_PMC_PASSES, kernels=LIVE_PMC_KERNELS):
     """Hardware counters of this command's kernels, COLLECTED NOW: one child run of this script per pass under
     ``rocprofv3 --pmc <counters>`` (separate passes, counters only, no tracing; the program itself after ``--``).  Children,
-    never an exec: this process has initialised the GPU.  Returns ``{kernel: {counter: mean per launch, "launches": n}}`` for
-    the kernels that ran, or ``None`` (no rocprofv3, a pass failed or timed out) -- the caller then falls back to the
-    committed records.  Derived figures (MI355X_MICROARCH.md): HBM-side bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 counts half
-    the bytes of a coalesced stream) + WRITE_SIZE[KiB] * 1024; MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8
-    XCDs * 1024 SIMDs)."""
+    never an exec: this process has initialised the GPU.  Returns ``(result, reason)``: ``{kernel: {counter: mean per launch,
+    "launches": n}}`` for the kernels that ran and ``""``, or ``None`` and why (no rocprofv3, already under a profiler, a pass
+    failed or timed out) -- the caller then falls back to the committed records and puts the reason into ``traffic_source``.
+    Never nests profilers: when this process itself runs under rocprofv3 (``rocprofv3 ... -- python bench.py``) nothing is
+    started -- the outer profiler's preload would initialise the GPU inside the inner ``rocprofv3`` launcher, whose exec into the
+    program is then the replacement of a GPU-initialised process this pool forbids.  Derived figures (MI355X_MICROARCH.md):
+    HBM-side bytes = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 counts half the bytes of a coalesced stream) + WRITE_SIZE[KiB] * 1024;
+    MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)."""
     import csv
     import glob
     import shutil
     import tempfile
+    if under_profiler():
+        return None, "not collected: this run is itself under a profiler (no nested rocprofv3)"
     if shutil.which("rocprofv3") is None:
-        return None
+        return None, "not collected: rocprofv3 not found"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--prewarm-s", "0",
-             "--batch", str(args.batch), "--dtype", args.dtype, "--no-live-pmc"] + (["--featurize-only"] if args.featurize_only else [])
+             "--batch", str(args.batch), "--dtype", args.dtype, "--no-live-pmc", "--stft-launches", "4"] + \
+            (["--featurize-only"] if args.featurize_only else [])
     res = {}
     tmp = tempfile.mkdtemp(prefix="cough_pmc_", dir="/tmp")
+    env = clean_child_env()
     try:
         for n, counters in enumerate(passes):
             out = os.path.join(tmp, f"pass{n}")
-            env = dict(os.environ, TMPDIR="/tmp")
-            env.pop("WORLD_SIZE", None)
-            try:
-                subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp",
-                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
-            except (subprocess.SubprocessError, OSError):
-                return None
+            why = run_child(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", *child], env, 90.0,
+                            os.path.join(tmp, f"pass{n}.err"))
+            if why:
+                return None, f"not collected: rocprofv3 --pmc {' '.join(counters)}: {why}"
             sums = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -136,10 +190,10 @@ def live_pmc(args, passes=LIVE_PMC_PASSES, kernels=LIVE_PMC_KERNELS):
             d["traffic"] = d["fetch"] + d["write"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE", 0) > 0:
             d["mfma_pipe_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
-    return res or None
+    return (res, "") if res else (None, "not collected: the counter files held none of the kernels")
 
 
-def stft_stage(pre, batches, launches: int = 210) -> dict:
+def stft_stage(pre, batches, launches: int = 210, warm: int = 60) -> dict:
     """The STFT stage on its own (cough_spectrogram = the reference's T.Spectrogram, preprocessing.py:131-136):
     waveform in, 257x101 power spectrogram out, timed with HIP events on the launch stream.  Reported beside the
     headline because BASELINE.json quotes an HBM fraction "for the STFT stage"; the fused featuriser above never
@@ -147,7 +201,7 @@ def stft_stage(pre, batches, launches: int = 210) -> dict:
     import torch
     b = batches[0].shape[0]
     spec = torch.empty((b, 257, 101), dtype=torch.float32, device=batches[0].device)
-    for i in range(60):
+    for i in range(warm):
         pre.spectrogram_batch(batches[i % len(batches)], out=spec)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -277,6 +331,8 @@ def parse_args(argv=None):
                     help="N > 1: steps per all-gather of logits (one bucketed exchange per this many steps)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect roofline.traffic with rocprofv3 --pmc child runs (N = 1); use the committed PMC record")
+    ap.add_argument("--stft-launches", type=int, default=210,
+                    help="timed launches of the stand-alone STFT stage (roofline_stft); the PMC child runs use a handful")
     ap.add_argument("--total-clips", type=int, default=0,
                     help="configs[3]: one pass over a stream of this many distinct clips (all ranks together); "
                          "overrides --steps and --rotate")
@@ -461,7 +517,9 @@ def main():
             traffic = int(traffic)
         if (world == 1 and not dist and not args.no_live_pmc and args.total_clips == 0 and Bk == B
                 and os.environ.get("COUGH_BENCH_LIVE_PMC", "1") == "1"):
-            live_all = live_pmc(args)
+            live_all, why_not = live_pmc(args)
+            if live_all is None and traffic_src:
+                traffic_src = f"{traffic_src} (live PMC {why_not})"
             live = (live_all or {}).get("featurize_kernel")
             if live is not None and "traffic" in live:
                 traffic = live["traffic"]
@@ -524,7 +582,8 @@ def main():
                 line["roofline_classifier"]["mfma_pipe_busy_source"] = "live: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (child run of this command)"
         stft_in = [b_ for b_ in batches[:8] if b_.shape[0] == B]
         if world == 1 and not dist and stft_in:
-            line["roofline_stft"] = stft_stage(pre, stft_in)
+            line["roofline_stft"] = stft_stage(pre, stft_in, launches=max(1, args.stft_launches),
+                                               warm=min(60, max(1, args.stft_launches)))
             lv = (live_all or {}).get("stft3_kernel")
             if lv is not None and "traffic" in lv:     # the child runs launched the stand-alone STFT kernel too
                 rs = line["roofline_stft"]

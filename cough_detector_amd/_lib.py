@@ -38,7 +38,8 @@ SYMBOLS = (
     "cough_amd_abi_version", "cough_amd_arch", "cough_amd_last_error",
     "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
     "cough_featurizer_num_frames", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
-    "cough_spectrogram",
+    "cough_spectrogram", "cough_featurizer_num_frames_for", "cough_featurizer_workspace_bytes_for", "cough_featurize_any",
+    "cough_spectrogram_any",
     "cough_resnet_create", "cough_resnet_create_ex", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
     "cough_resblock_create", "cough_resblock_destroy", "cough_resblock_workspace_bytes", "cough_resblock_out_shape",
     "cough_resblock_forward",
@@ -117,6 +118,11 @@ def load() -> C.CDLL:
         lib.cough_featurizer_workspace_bytes.argtypes = [vp, i]
         lib.cough_featurizer_workspace_bytes.restype = C.c_size_t
         lib.cough_featurize_ws.argtypes = [vp, vp, ll, vp, i, i, vp, C.c_size_t, vp]
+        lib.cough_featurizer_num_frames_for.argtypes = [vp, i]
+        lib.cough_featurizer_workspace_bytes_for.argtypes = [vp, i, i]
+        lib.cough_featurizer_workspace_bytes_for.restype = C.c_size_t
+        lib.cough_featurize_any.argtypes = [vp, vp, ll, i, vp, i, i, vp, C.c_size_t, vp]
+        lib.cough_spectrogram_any.argtypes = [vp, vp, ll, i, vp, i, i, vp]
         lib.cough_resnet_create.argtypes = [C.POINTER(vp), C.POINTER(ResNetWeights), i]
         lib.cough_resnet_create_ex.argtypes = [C.POINTER(vp), i, C.POINTER(i), C.POINTER(ConvBN), C.POINTER(ResBlockWeights),
                                                _FP, _FP, C.c_float, i]
@@ -153,7 +159,7 @@ def load() -> C.CDLL:
         lib.cough_pre_emphasis.argtypes = [vp, ll, vp, ll, i, i, C.c_float, vp]
         lib.cough_compute_deltas.argtypes = [vp, vp, ll, i, vp]
         lib.cough_pcen.argtypes = [vp, vp, ll, i, C.c_float, C.c_float, C.c_float, C.c_float, vp]
-        if lib.cough_amd_abi_version() != 4:
+        if lib.cough_amd_abi_version() != 5:
             raise RuntimeError("libcough_amd.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

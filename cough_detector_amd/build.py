@@ -20,7 +20,10 @@ SOURCES = ("api.hip", "featurize.hip", "featurize_generic.hip", "spectrogram.hip
 # -fno-slp-vectorize: left alone, -O3 packs adjacent f32 adds / multiplies of the FFT butterflies into v_pk_*_f32, which issue
 # slower than the two scalar operations they replace on gfx950 (same-box A/B: K1 -2.4 %, STFT stage -3.2 %, classifier unchanged;
 # profiles/r04_flag_ab.txt)
-CFLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+# -fvisibility=hidden: the shared object exports the entry points include/cough_amd.h declares (its `#pragma GCC visibility
+# push(default)`) and nothing else -- no C++-mangled internals, no std::vector instantiations
+CFLAGS = ["-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
+          "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 FLAGS = CFLAGS + ["-shared"]          # one-shot command line (the diagnostic tools build variants with it)
 
 
@@ -35,6 +38,7 @@ def _headers_mtime() -> float:
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(HERE, "..", "include", "cough_amd.h"))
     deps.append(os.path.abspath(__file__))   # the flags live here
+    deps.append(os.path.join(CSRC, "exports.map"))
     return max(os.path.getmtime(d) for d in deps)
 
 
@@ -66,7 +70,8 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+           "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

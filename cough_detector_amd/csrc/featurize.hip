@@ -627,7 +627,9 @@ struct cough_featurizer {
     int nbase;           // rows the featurise kernel writes (mel [+ MFCC, delta, delta-delta])
     cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
     int n_cus;           // compute units of the device the featuriser was created on
-    cough::GenFeat* gen; // non-null: a geometry the tuned kernel does not cover -> featurize_generic.hip
+    bool tuned;          // the one-launch kernel serves the constructor's segment length
+    cough::GenFeat* gen; // the generic kernel chain's tables (featurize_generic.hip): every geometry the tuned kernel does not
+                         // cover, and -- for every featuriser -- waveforms of any other length (extract_features of any N)
 };
 
 extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
@@ -687,12 +689,12 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
         for (int m = 0; m < NMEL; ++m) t.dct_t[NMFCC][m] = 0.f;
     }
     GenFeat* gen = nullptr;
-    if (!tuned)
-        if (int e = gen_feat_create(&gen, cfg, window, mel_fb, dct)) return e;
+    if (int e = gen_feat_create(&gen, cfg, window, mel_fb, dct)) return e;
 
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
     f->gen = gen;
+    f->tuned = tuned;
     f->nbase = cfg->use_mfcc ? cfg->n_mels + 2 * cfg->n_mfcc + (cfg->use_delta_delta ? cfg->n_mfcc : 0) : cfg->n_mels;
     f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
     f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
@@ -720,7 +722,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
 }
 
 #ifdef COUGH_K1_STAMPS
-extern "C" int cough_debug_set_stamp_buffer(void* d_buf) {
+extern "C" __attribute__((visibility("default"))) int cough_debug_set_stamp_buffer(void* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
 }
 #endif
@@ -734,8 +736,9 @@ extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
 }
 
 extern "C" int cough_featurizer_num_features(const cough_featurizer* f) { return f ? f->nfeat : -1; }
-extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) {
-    return !f ? -1 : f->gen ? cough::gen_num_frames(f->gen) : cough::NFRAMES;
+extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return !f ? -1 : cough::gen_frames(f->gen, 0); }
+extern "C" int cough_featurizer_num_frames_for(const cough_featurizer* f, int n_samples) {
+    return !f || n_samples < 0 ? -1 : cough::gen_frames(f->gen, n_samples);
 }
 
 namespace cough {
@@ -747,22 +750,24 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
+bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->tuned && (n_samples <= 0 || n_samples == NS); }
 bool featurizer_stem_fusable(const cough_featurizer* f) {
-    return !f->gen && f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+    return f->tuned && f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
 }
-size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips) {
-    if (f->gen) return gen_workspace_bytes(f->gen, f->cfg, n_clips);
+size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
+    if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
     return f->contrast.n_bands > 0 && n_clips > 0 ? contrast_workspace_bytes(n_clips) : 0;
 }
 
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
-                     int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace, size_t workspace_bytes) {
+                     int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace, size_t workspace_bytes,
+                     int n_samples) {
     COUGH_REQUIRE(f && d_wav && (d_feat || stem), COUGH_EINVAL, "cough_featurize: NULL argument");
-    COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0");
-    if (f->gen) {
+    COUGH_REQUIRE(n_clips >= 0 && n_samples >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0 or n_samples < 0");
+    if (!featurizer_tuned(f, n_samples)) {
         COUGH_REQUIRE(!stem, COUGH_EUNSUPPORTED, "the fused stem needs the shipped 90-row feature layout");
         if (n_clips == 0) return COUGH_OK;
-        return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase, n_clips,
+        return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, n_samples, d_feat, f->nfeat, f->nbase, n_clips,
                              (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0, d_workspace, workspace_bytes, stream);
     }
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
@@ -796,6 +801,15 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
 
 extern "C" size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips) {
     return f ? cough::featurizer_workspace_bytes(f, n_clips) : 0;
+}
+extern "C" size_t cough_featurizer_workspace_bytes_for(const cough_featurizer* f, int n_samples, int n_clips) {
+    return f && n_samples >= 0 ? cough::featurizer_workspace_bytes(f, n_clips, n_samples) : 0;
+}
+extern "C" int cough_featurize_any(const cough_featurizer* f, const float* d_wav, long long wav_stride, int n_samples,
+                                   float* d_feat, int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    COUGH_REQUIRE(d_feat, COUGH_EINVAL, "cough_featurize_any: NULL argument");
+    return cough::launch_featurize(f, d_wav, wav_stride, d_feat, n_clips, flags, nullptr, static_cast<hipStream_t>(stream),
+                                   d_workspace, workspace_bytes, n_samples);
 }
 
 extern "C" int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,

@@ -415,7 +415,6 @@ __global__ __launch_bounds__(256) void gen_stft_dft_kernel(const float* __restri
             __syncthreads();
             if (has_a) {
                 const int gn = tab.groups - (n0 >> 3) < G_DFT_KC / 8 ? tab.groups - (n0 >> 3) : G_DFT_KC / 8;   // groups of 8 n left
-#pragma unroll 2
                 for (int gi = 0; gi < gn; ++gi) {
                     const int g = (n0 >> 3) + gi;
                     const float4 ca = nca, sa = nsa, cb = ncb, sb = nsb;
@@ -706,7 +705,8 @@ size_t pow2_lds_bytes(int nfft) { return size_t(4) * 2 * (nfft / 2) * 8 + size_t
 }  // namespace
 
 struct GenFeat {
-    int N, hop, T, n_mels, n_mfcc, sample_rate;
+    int N, hop, T, n_mels, n_mfcc, sample_rate;   // N / T: the constructor's segment and its frame count -- the tables hold for ANY
+                                                  // waveform length, which is a launch parameter (gen_frames)
     int nfft, nfreq;       // n_fft (16 .. 2048) and n_fft / 2 + 1
     char* d_blob;
     const float* win;      // [n_fft] caller's window centred in the frame
@@ -726,19 +726,19 @@ namespace {
 // one STFT launch of the chain: the register radix-16 x radix-16 kernel at n_fft = 512, the Stockham kernel for the other
 // powers of two, the direct DFT for everything else
 template <bool MAG, bool MEL>
-void gen_launch_stft(const GenFeat* g, const float* w, long long wav_stride, int nc, const float* win, const float* peaks,
+void gen_launch_stft(const GenFeat* g, int N, int T, const float* w, long long wav_stride, int nc, const float* win, const float* peaks,
                      int pre_emph, float coef, float* out, const GenMel& mel, hipStream_t stream) {
     if (g->nfft == G_NFFT) {
-        const long long n_rows = (long long)nc * g->T;
+        const long long n_rows = (long long)nc * T;
         hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_FPB - 1) / G_FPB)), dim3(256), 0, stream, w,
-                           wav_stride, g->N, g->hop, g->T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows);
+                           wav_stride, N, g->hop, T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows);
     } else if (g->nfft >= 64 && (g->nfft & (g->nfft - 1)) == 0) {
-        hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((g->T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
-                           wav_stride, g->N, g->hop, g->T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
+        hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
+                           wav_stride, N, g->hop, T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
     } else {
-        const long long n_rows = (long long)nc * g->T;
+        const long long n_rows = (long long)nc * T;
         hipLaunchKernelGGL((gen_stft_dft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_DFT_M - 1) / G_DFT_M)), dim3(256),
-                           dft_lds_bytes(g->dft.pitch), stream, w, wav_stride, g->N, g->hop, g->T, g->nfft, win, g->dft, peaks, pre_emph,
+                           dft_lds_bytes(g->dft.pitch), stream, w, wav_stride, N, g->hop, T, g->nfft, win, g->dft, peaks, pre_emph,
                            coef, out, mel, n_rows);
     }
 }
@@ -748,7 +748,7 @@ int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* wi
     const int nfft = cfg->n_fft, nfreq = nfft / 2 + 1;
     COUGH_REQUIRE(nfft >= 16 && nfft <= 2048, COUGH_EUNSUPPORTED,
                   "n_fft = %d: the HIP path implements 16 .. 2048 (512 on the register FFT kernels, the other powers of two "
-                  "from 64 on a radix-2 kernel, anything else by direct DFT)", nfft);
+                  "from 64 on a radix-4 Stockham kernel, anything else by direct DFT)", nfft);
     COUGH_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= nfft, COUGH_EUNSUPPORTED,
                   "win_length = %d: need 1 <= win_length <= n_fft", cfg->win_length);
     COUGH_REQUIRE(cfg->hop_length >= 1, COUGH_EINVAL, "hop_length = %d", cfg->hop_length);
@@ -909,17 +909,21 @@ void gen_feat_destroy(GenFeat* g) {
     delete g;
 }
 
-int gen_num_frames(const GenFeat* g) { return g->T; }
 int gen_segment_samples(const GenFeat* g) { return g->N; }
+// frames of torch.stft(center=True) for a waveform of n_samples (0: the constructor's segment): n / hop + 1 for an even n_fft
+// (get_expected_time_frames(), :532-534), one sample less of signal for an odd one
+int gen_frames(const GenFeat* g, int n_samples) {
+    return n_samples <= 0 ? g->T : (n_samples - (g->nfft & 1)) / g->hop + 1;
+}
 
 namespace {
 struct GenCarve {
     int sub;                 // clips per sub-batch
     size_t o_peaks, o_stat, o_P, o_M, o_mel, total;
 };
-GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
+GenCarve gen_carve(const GenFeat* g, bool contrast, int T, int n_clips) {
     GenCarve c;
-    const size_t spec = size_t(g->nfreq) * g->T * 4, mel = size_t(g->n_mels) * g->T * 4;
+    const size_t spec = size_t(g->nfreq) * T * 4, mel = size_t(g->n_mels) * T * 4;
     const size_t per = spec * (contrast ? 2 : 0) + mel;   // the spectrograms exist only for the contrast rows
     size_t sub = G_SUB_BYTES / per;
     if (sub < 1) sub = 1;
@@ -936,28 +940,34 @@ GenCarve gen_carve(const GenFeat* g, bool contrast, int n_clips) {
 }
 }  // namespace
 
-size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_clips) {
-    return n_clips > 0 ? gen_carve(g, cfg.use_spectral_contrast != 0, n_clips).total : 0;
+size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_samples, int n_clips) {
+    return n_clips > 0 ? gen_carve(g, cfg.use_spectral_contrast != 0, gen_frames(g, n_samples), n_clips).total : 0;
 }
 
-int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, int n_samples, float* d_spec, int n_clips, int flags,
                     hipStream_t stream) {
-    COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_spectrogram: row stride %lld < segment of %d samples", wav_stride, g->N);
+    const int N = n_samples > 0 ? n_samples : g->N, T = gen_frames(g, N);
+    COUGH_REQUIRE(N > g->nfft / 2, COUGH_EINVAL, "cough_spectrogram: %d samples: reflect padding needs more than n_fft / 2 = %d", N,
+                  g->nfft / 2);
+    COUGH_REQUIRE(wav_stride >= N, COUGH_EINVAL, "cough_spectrogram: row stride %lld < %d samples", wav_stride, N);
     const bool full = flags & COUGH_SPEC_FULL_WINDOW, mag = flags & COUGH_SPEC_MAGNITUDE;
     const float* win = full ? g->win_full : g->win;
     const GenMel none{0, nullptr, nullptr, nullptr, nullptr, 0};
-    if (mag) gen_launch_stft<true, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
-    else gen_launch_stft<false, false>(g, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
+    if (mag) gen_launch_stft<true, false>(g, N, T, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
+    else gen_launch_stft<false, false>(g, N, T, d_wav, wav_stride, n_clips, win, nullptr, 0, 0.f, d_spec, none, stream);
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
 
 int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
-                  long long wav_stride, float* d_feat, int nfeat, int nbase, int n_clips, int normalize, void* d_workspace,
-                  size_t workspace_bytes, hipStream_t stream) {
-    COUGH_REQUIRE(wav_stride >= g->N, COUGH_EINVAL, "cough_featurize: row stride %lld < segment of %d samples", wav_stride, g->N);
+                  long long wav_stride, int n_samples, float* d_feat, int nfeat, int nbase, int n_clips, int normalize,
+                  void* d_workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int N = n_samples > 0 ? n_samples : g->N, T = gen_frames(g, N);
+    COUGH_REQUIRE(N > g->nfft / 2, COUGH_EINVAL, "cough_featurize: %d samples: the reflect padding of torch.stft(center=True) needs "
+                  "more than n_fft / 2 = %d", N, g->nfft / 2);
+    COUGH_REQUIRE(wav_stride >= N, COUGH_EINVAL, "cough_featurize: row stride %lld < %d samples", wav_stride, N);
     const bool want_contrast = contrast.n_bands > 0;
-    const GenCarve c = gen_carve(g, want_contrast, n_clips);
+    const GenCarve c = gen_carve(g, want_contrast, T, n_clips);
     COUGH_REQUIRE(d_workspace && workspace_bytes >= c.total, COUGH_EWORKSPACE,
                   "this featuriser geometry runs on the generic kernel chain and needs a workspace of "
                   "cough_featurizer_workspace_bytes() = %zu bytes (cough_featurize_ws)", c.total);
@@ -968,17 +978,17 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
     float* P = reinterpret_cast<float*>(ws + c.o_P);
     float* M = reinterpret_cast<float*>(ws + c.o_M);
     float* mel = reinterpret_cast<float*>(ws + c.o_mel);
-    const int T = g->T, n_mels = g->n_mels, n_mfcc = g->n_mfcc;
+    const int n_mels = g->n_mels, n_mfcc = g->n_mfcc;
     for (int c0 = 0; c0 < n_clips; c0 += c.sub) {
         const int nc = n_clips - c0 < c.sub ? n_clips - c0 : c.sub;
         const float* w = d_wav + (long long)c0 * wav_stride;
         float* feat = d_feat + (long long)c0 * nfeat * T;
         const float* pk = normalize ? peaks : nullptr;
-        if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, g->N, peaks);
+        if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, N, peaks);
         const dim3 gt((T + G_TT - 1) / G_TT, nc);
         // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
         const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, g->n_taps}, none{0, nullptr, nullptr, nullptr, nullptr, 0};
-        gen_launch_stft<false, true>(g, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
+        gen_launch_stft<false, true>(g, N, T, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
         hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
                            g->dct_t, feat, nfeat);
@@ -989,8 +999,8 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         }
         if (want_contrast) {
             // from the un-emphasised (normalised) signal (:476-478)
-            gen_launch_stft<false, false>(g, w, wav_stride, nc, g->win, pk, 0, 0.f, P, none, stream);
-            gen_launch_stft<true, false>(g, w, wav_stride, nc, g->win_full, pk, 0, 0.f, M, none, stream);
+            gen_launch_stft<false, false>(g, N, T, w, wav_stride, nc, g->win, pk, 0, 0.f, P, none, stream);
+            gen_launch_stft<true, false>(g, N, T, w, wav_stride, nc, g->win_full, pk, 0, 0.f, M, none, stream);
             hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, g->nfreq, contrast, g->freqs,
                                float(g->sample_rate) / 2.0f, feat, nfeat, nbase);
             hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);

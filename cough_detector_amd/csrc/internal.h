@@ -20,10 +20,11 @@ struct StemFuse {
 };
 
 // featurize.hip: d_feat may be nullptr when `stem` is given (features not materialised)
+// n_samples: length of every waveform row (0 = the constructor's segment; another length runs on the generic chain)
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
                      int flags, const StemFuse* stem, hipStream_t stream, void* d_workspace = nullptr,
-                     size_t workspace_bytes = 0);
-size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
+                     size_t workspace_bytes = 0, int n_samples = 0);
+size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples = 0);
 int featurizer_num_features(const cough_featurizer* f);
 bool featurizer_stem_fusable(const cough_featurizer* f);   // shipped 90-row layout, no pre-emphasis, no PCEN
 
@@ -52,15 +53,17 @@ int stft_prepare_device(int* n_cus);
 struct GenFeat;
 int gen_feat_create(GenFeat** out, const cough_feat_config* cfg, const float* window, const float* mel_fb, const float* dct);
 void gen_feat_destroy(GenFeat* g);
-int gen_num_frames(const GenFeat* g);
+// the tables hold for waveforms of ANY length: n_samples is a launch parameter (0 = the constructor's segment)
+int gen_frames(const GenFeat* g, int n_samples);
 int gen_segment_samples(const GenFeat* g);
-size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_clips);
-int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
+size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_samples, int n_clips);
+int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, int n_samples, float* d_spec, int n_clips, int flags,
                     hipStream_t stream);
 int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
-                  long long wav_stride, float* d_feat, int nfeat, int nbase, int n_clips, int normalize, void* d_workspace,
-                  size_t workspace_bytes, hipStream_t stream);
-const GenFeat* featurizer_generic(const cough_featurizer* f);   // nullptr: the tuned kernel serves this featuriser
+                  long long wav_stride, int n_samples, float* d_feat, int nfeat, int nbase, int n_clips, int normalize,
+                  void* d_workspace, size_t workspace_bytes, hipStream_t stream);
+const GenFeat* featurizer_generic(const cough_featurizer* f);   // every featuriser has the generic chain's tables
+bool featurizer_tuned(const cough_featurizer* f, int n_samples = 0);   // the one-launch kernel serves waveforms of this length
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream);
 

@@ -1156,7 +1156,7 @@ int forward_impl(const cough_resnet* m, const float* d_feat, int n, const Shapes
 }  // namespace cough
 
 #ifdef COUGH_K1_STAMPS
-extern "C" int cough_debug_set_rb_stamp_buffer(void* d_buf) {
+extern "C" __attribute__((visibility("default"))) int cough_debug_set_rb_stamp_buffer(void* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_rb_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
 }
 #endif

@@ -472,25 +472,31 @@ int stft_prepare_device(int* n_cus) {
 }  // namespace cough
 
 #ifdef COUGH_K1_STAMPS
-extern "C" int cough_debug_set_stft_stamp_buffer(void* d_buf) {
+extern "C" __attribute__((visibility("default"))) int cough_debug_set_stft_stamp_buffer(void* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(cough::g_stft_stamp_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 3;
 }
 #endif
 
-extern "C" int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_spec,
-                                 int n_clips, int flags, void* stream) {
+extern "C" int cough_spectrogram_any(const cough_featurizer* f, const float* d_wav, long long wav_stride, int n_samples,
+                                     float* d_spec, int n_clips, int flags, void* stream) {
     using namespace cough;
     COUGH_REQUIRE(f && d_wav && d_spec, COUGH_EINVAL, "cough_spectrogram: NULL argument");
-    COUGH_REQUIRE(n_clips >= 0, COUGH_EINVAL, "cough_spectrogram: n_clips < 0");
+    COUGH_REQUIRE(n_clips >= 0 && n_samples >= 0, COUGH_EINVAL, "cough_spectrogram: n_clips < 0 or n_samples < 0");
     COUGH_REQUIRE((flags & ~(COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW)) == 0, COUGH_EINVAL,
                   "cough_spectrogram: unknown flag bits 0x%x", flags);
-    if (const GenFeat* g = featurizer_generic(f)) {   // a geometry the persistent kernel is not built for
+    if (!featurizer_tuned(f, n_samples)) {   // a geometry / a waveform length the persistent kernel is not built for
         if (n_clips == 0) return COUGH_OK;
-        return gen_spectrogram(g, d_wav, wav_stride, d_spec, n_clips, flags, static_cast<hipStream_t>(stream));
+        return gen_spectrogram(featurizer_generic(f), d_wav, wav_stride, n_samples, d_spec, n_clips, flags,
+                               static_cast<hipStream_t>(stream));
     }
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_spectrogram: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
     if (n_clips == 0) return COUGH_OK;
     return launch_stft(featurizer_stft_view(f), d_wav, wav_stride, d_spec, n_clips, flags,
                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_spec,
+                                 int n_clips, int flags, void* stream) {
+    return cough_spectrogram_any(f, d_wav, wav_stride, 0, d_spec, n_clips, flags, stream);
 }

@@ -25,7 +25,7 @@ import torch
 
 from .model import create_model
 from .pipeline import CoughPipeline
-from .preprocessing import RealtimePreprocessor
+from .preprocessing import RealtimePreprocessor, RecentLog
 
 
 def num_features_from_config(config: dict) -> int:
@@ -43,7 +43,7 @@ def num_features_from_config(config: dict) -> int:
 class CoughDetectorInference:
     def __init__(self, model_path: str, device: str = "auto", confidence_threshold: float = 0.5,
                  smoothing_window: int = 3, debounce_seconds: float = 0.5, verbose: bool = True,
-                 clock: Optional[Callable[[], float]] = None, compute_dtype: str = "bf16x3"):
+                 clock: Optional[Callable[[], float]] = None, compute_dtype: str = "bf16x3", prob_history: int = 4096):
         # compute_dtype: "bf16x3" (default: split-bf16 MFMA, logits within 1e-3 of the f32 reference for all three model
         # types, several times faster) or "fp32" (exact-f32 MFMA: CPU-reference numerics)
         self.verbose = verbose
@@ -77,7 +77,9 @@ class CoughDetectorInference:
         self.last_detection_time = 0
         self.on_cough_detected: Optional[Callable[[datetime, float], None]] = None
         self._clock = clock or (lambda: datetime.now().timestamp())
-        self.window_probs = []      # every per-window cough probability seen (diagnostics / parity tests)
+        # the most recent per-window cough probabilities (diagnostics / parity tests; bounded: `prob_history` entries)
+        self.window_probs = RecentLog(prob_history)
+        self.windows_seen = 0
 
     def _load_model(self, model_path):
         if self.verbose:
@@ -126,6 +128,7 @@ class CoughDetectorInference:
         probs = p2[:, 1].to("cpu").tolist()                                      # the one host sync of the chunk
         for confidence in probs:
             self.window_probs.append(confidence)
+            self.windows_seen += 1
             self.prediction_history.append(confidence)
             smoothed = float(np.mean(self.prediction_history))
             now = self._clock()
@@ -160,8 +163,8 @@ class RealtimeQueueDetector:
         self.running = False
         self.audio_queue: "queue.Queue" = queue.Queue()
         self.on_detection: Optional[Callable[[datetime, float], None]] = None
-        self.detections = []            # (stream time or wall time, confidence)
-        self.errors = []                # the reference prints and goes on (:323-324); kept for the caller as well
+        self.detections = RecentLog(4096)   # (stream time or wall time, confidence), the most recent ones
+        self.errors = RecentLog(256)        # the reference prints and goes on (:323-324); kept for the caller as well
         self.verbose = verbose
         self._consumed = 0
         self._clock_from_samples = clock_from_samples

@@ -19,7 +19,7 @@ from .preprocessing import AudioPreprocessor, _cuda_device
 class CoughPipeline:
     def __init__(self, preprocessor: AudioPreprocessor, model: torch.nn.Module):
         self.pre, self.model = preprocessor, model
-        self._ws: Optional[torch.Tensor] = None
+        self._ws = {}   # stream -> workspace: threads / streams sharing this pipeline never share scratch
 
     def _run(self, waveforms: torch.Tensor, normalize: bool, want_probs: bool, return_features: bool,
              events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None):
@@ -56,14 +56,17 @@ class CoughPipeline:
         if b:
             lib, fh, mh = _lib.load(), self.pre._native(), self.model._native()
             need = lib.cough_pipeline_workspace_bytes(fh, mh, b)
-            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._ws.get(stream)
+            if ws is None or ws.numel() < need or ws.device != dev:
+                if ws is None and len(self._ws) >= 8:
+                    self._ws.pop(next(iter(self._ws)))
+                ws = self._ws[stream] = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.cough_pipeline_forward(
                 fh, mh, w.data_ptr(), w.stride(0) if b > 1 else n_samples, b, _lib.FEAT_NORMALIZE if normalize else 0,
                 feats.data_ptr() if return_features else None, logits.data_ptr(),
                 probs.data_ptr() if want_probs else None, preds.data_ptr() if want_probs else None,
-                self._ws.data_ptr(), self._ws.numel(), stream,
+                ws.data_ptr(), ws.numel(), stream,
                 events[0].cuda_event if events else None, events[1].cuda_event if events else None),
                 "cough_pipeline_forward")
         return logits, probs, preds, feats

@@ -11,7 +11,8 @@ Differences a caller can observe:
   passes, or "cuda"); compute is always on the MI355X -- there is no CPU fallback.
 * ``extract_features`` additionally accepts ``(B, N)`` / ``(B, 1, N)`` batches and returns
   ``(B, F, T)`` with the reference's per-clip reduction semantics; like the reference it takes a waveform of ANY
-  length N (T = 1 + N // hop_length): ``segment_samples`` runs on the tuned kernel, other lengths on the generic chain.
+  length N (T = 1 + N // hop_length): ``segment_samples`` runs on the tuned kernel, other lengths on the generic chain --
+  through the same handle (the length is a launch parameter).
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
   spectral contrast + centroid) for every geometry with ``n_fft`` in 16..2048: any ``sample_rate`` /
   ``hop_length`` / ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The
@@ -23,6 +24,7 @@ Differences a caller can observe:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import warnings
 from typing import List, Optional, Tuple
 
@@ -122,34 +124,39 @@ class AudioPreprocessor:
         self._mel_fb = _tables.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
         self._dct = _tables.dct_matrix(n_mfcc, n_mels)
         self._handle: Optional[C.c_void_p] = None
-        self._length_handles = {}                   # other waveform lengths -> featuriser handles (extract_features of any N)
-        self._retired = []                          # handles evicted from that cache (freed in __del__)
-        self._ws: Optional[torch.Tensor] = None     # scratch of the spectral-contrast rows / the generic kernel chain
+        self._handle_lock = threading.Lock()
+        self._ws = {}                               # stream -> scratch of the spectral-contrast rows / the generic kernel chain
         self._resamplers = {}
 
     # ------------------------------------------------------------------ native handle
-    MAX_LENGTH_HANDLES = 16
-
-    def _native(self, n_samples: Optional[int] = None) -> C.c_void_p:
-        """The featuriser handle for windows of ``n_samples`` (default: ``segment_samples``).  The reference's
-        ``extract_features`` takes a waveform of ANY length (T = 1 + N // hop_length, ``src/preprocessing.py:432-489``); a
-        length other than the constructor's segment gets a handle of its own (generic kernel chain), cached per length."""
-        if n_samples is not None and n_samples != self.segment_samples:
-            h = self._length_handles.get(n_samples)
-            if h is None:
-                if n_samples <= self.n_fft // 2:
-                    raise ValueError(f"a waveform of {n_samples} samples is shorter than the reflect padding of "
-                                     f"torch.stft(center=True) (needs more than n_fft // 2 = {self.n_fft // 2})")
-                if len(self._length_handles) >= self.MAX_LENGTH_HANDLES:          # retire the oldest length
-                    # not destroyed here: another thread / a launch in flight may still use its tables (a handle is ~20 KB of
-                    # device memory); retired handles are freed with the preprocessor
-                    old = next(iter(self._length_handles))
-                    self._retired.append(self._length_handles.pop(old))
-                h = self._length_handles[n_samples] = self._create_handle(n_samples)
-            return h
+    def _native(self) -> C.c_void_p:
+        """The ONE featuriser handle of this preprocessor.  None of its tables depends on the waveform length -- the reference's
+        ``extract_features`` takes a waveform of ANY length (T = 1 + N // hop_length, ``src/preprocessing.py:432-489``) -- so the
+        length is a launch parameter (``cough_featurize_any``): the constructor's segment runs on the tuned kernel where there is
+        one, every other length on the generic kernel chain, with the same tables."""
         if self._handle is None:
-            self._handle = self._create_handle(self.segment_samples)
+            with self._handle_lock:
+                if self._handle is None:
+                    self._handle = self._create_handle(self.segment_samples)
         return self._handle
+
+    def _check_length(self, n_samples: int) -> None:
+        if n_samples <= self.n_fft // 2:
+            raise ValueError(f"a waveform of {n_samples} samples is shorter than the reflect padding of "
+                             f"torch.stft(center=True) (needs more than n_fft // 2 = {self.n_fft // 2})")
+
+    MAX_STREAM_WORKSPACES = 8
+
+    def _workspace(self, need: int, dev: torch.device, stream: int) -> torch.Tensor:
+        """Scratch for one launch on ``stream``.  One buffer per stream: two threads / streams sharing this preprocessor never
+        share scratch (``include/cough_amd.h``: "each with its own workspace and stream"), and a buffer that is replaced goes back
+        to torch's caching allocator, which hands it out again only in stream order."""
+        ws = self._ws.get(stream)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            if ws is None and len(self._ws) >= self.MAX_STREAM_WORKSPACES:
+                self._ws.pop(next(iter(self._ws)))
+            ws = self._ws[stream] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws
 
     def _create_handle(self, n_samples: int) -> C.c_void_p:
         lib = _lib.load()
@@ -170,15 +177,12 @@ class AudioPreprocessor:
         return h
 
     def __del__(self):
-        handles = [getattr(self, "_handle", None)] + list(getattr(self, "_length_handles", {}).values()) + \
-            list(getattr(self, "_retired", []))
-        self._handle, self._length_handles, self._retired = None, {}, []
-        for h in handles:
-            if h is not None:
-                try:
-                    _lib.load().cough_featurizer_destroy(h)
-                except Exception:
-                    pass
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None:
+            try:
+                _lib.load().cough_featurizer_destroy(h)
+            except Exception:
+                pass
 
     # ------------------------------------------------------------------ reference helpers (host plumbing)
     def load_audio(self, path: str):
@@ -310,12 +314,13 @@ class AudioPreprocessor:
     def featurize_batch(self, waveforms: torch.Tensor, normalize: bool = False,
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(B, N) float32 on the GPU -> (B, F, 1 + N // hop_length) float32 on the GPU (stream-ordered, no host sync);
-        N = ``segment_samples`` is the tuned path, any other length runs on the generic kernel chain with a handle
-        cached per length.  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
+        N = ``segment_samples`` is the tuned path, any other length runs on the generic kernel chain (same handle, the
+        length is a launch parameter).  ``normalize=True`` fuses ``normalize()`` per clip into the kernel."""
         _check_waveform(waveforms, "featurize_batch")
         if waveforms.dim() != 2 or waveforms.shape[1] < 1:
             raise ValueError(f"featurize_batch: expected (B, N), got {tuple(waveforms.shape)}")
         n_samples = waveforms.shape[1]
+        self._check_length(n_samples)
         dev = _cuda_device()
         w = waveforms.to(device=dev, dtype=torch.float32)
         if w.stride(1) != 1 or w.stride(0) % 4 != 0 or w.data_ptr() % 16 != 0:
@@ -330,16 +335,12 @@ class AudioPreprocessor:
             return out
         stream = torch.cuda.current_stream(dev).cuda_stream
         stride = w.stride(0) if b > 1 else n_samples
-        lib, h = _lib.load(), self._native(n_samples)
-        need = lib.cough_featurizer_workspace_bytes(h, b)      # non-zero with spectral contrast / on the generic chain
-        ws = None
-        if need:
-            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            ws = self._ws
-        _lib.check(lib.cough_featurize_ws(h, w.data_ptr(), stride, out.data_ptr(), b,
-                                          _lib.FEAT_NORMALIZE if normalize else 0,
-                                          ws.data_ptr() if need else None, need, stream), "cough_featurize_ws")
+        lib, h = _lib.load(), self._native()
+        need = lib.cough_featurizer_workspace_bytes_for(h, n_samples, b)   # non-zero with spectral contrast / on the generic chain
+        ws = self._workspace(need, dev, stream) if need else None
+        _lib.check(lib.cough_featurize_any(h, w.data_ptr(), stride, n_samples, out.data_ptr(), b,
+                                           _lib.FEAT_NORMALIZE if normalize else 0,
+                                           ws.data_ptr() if need else None, need, stream), "cough_featurize_any")
         return out
 
     def spectrogram_batch(self, waveforms: torch.Tensor, power: float = 2.0, full_window: bool = False,
@@ -352,6 +353,7 @@ class AudioPreprocessor:
         if waveforms.dim() != 2 or waveforms.shape[1] < 1:
             raise ValueError(f"spectrogram_batch: expected (B, N), got {tuple(waveforms.shape)}")
         n_samples = waveforms.shape[1]
+        self._check_length(n_samples)
         if power not in (1.0, 2.0):
             raise ValueError("spectrogram_batch: power must be 1.0 or 2.0")
         dev = _cuda_device()
@@ -366,9 +368,9 @@ class AudioPreprocessor:
         if b == 0:
             return out
         flags = (_lib.SPEC_MAGNITUDE if power == 1.0 else 0) | (_lib.SPEC_FULL_WINDOW if full_window else 0)
-        _lib.check(_lib.load().cough_spectrogram(self._native(n_samples), w.data_ptr(), w.stride(0) if b > 1 else
-                                                 n_samples, out.data_ptr(), b, flags,
-                                                 torch.cuda.current_stream(dev).cuda_stream), "cough_spectrogram")
+        _lib.check(_lib.load().cough_spectrogram_any(self._native(), w.data_ptr(), w.stride(0) if b > 1 else n_samples,
+                                                     n_samples, out.data_ptr(), b, flags,
+                                                     torch.cuda.current_stream(dev).cuda_stream), "cough_spectrogram_any")
         return out
 
     def extract_features(self, waveform: torch.Tensor) -> torch.Tensor:
@@ -412,6 +414,22 @@ class AudioPreprocessor:
         return self.process(*self.load_audio(path))
 
 
+class RecentLog(list):
+    """A list that keeps only the most recent ``maxlen`` appended values (amortised O(1) append): the per-window
+    probability logs of the engines are diagnostics, and a detector that runs for months must not grow with them."""
+
+    def __init__(self, maxlen: int = 4096):
+        super().__init__()
+        if maxlen < 1:
+            raise ValueError(f"RecentLog: maxlen={maxlen} must be positive")
+        self.maxlen = int(maxlen)
+
+    def append(self, value) -> None:
+        super().append(value)
+        if len(self) >= 2 * self.maxlen:
+            del self[:len(self) - self.maxlen]
+
+
 class RealtimePreprocessor(AudioPreprocessor):
     """Sliding-window front end: append chunks, emit one feature image per complete window.
     All complete windows of a call are featurised by ONE kernel launch (batch = windows)."""
@@ -422,6 +440,10 @@ class RealtimePreprocessor(AudioPreprocessor):
         self.hop_duration = hop_duration
         self.window_samples = int(self.sample_rate * window_duration)
         self.hop_samples = int(self.sample_rate * hop_duration)
+        if self.hop_samples < 1:
+            # the reference's add_audio would never advance its buffer (an endless `while`, src/preprocessing.py:597-610)
+            raise ValueError(f"RealtimePreprocessor: hop_duration={hop_duration} gives a hop of {self.hop_samples} samples; "
+                             "it must be at least one sample")
         self.buffer = torch.zeros(1, 0)
 
     def take_windows(self, audio_chunk: torch.Tensor) -> Optional[torch.Tensor]:

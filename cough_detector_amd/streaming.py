@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from .pipeline import CoughPipeline
-from .preprocessing import AudioPreprocessor
+from .preprocessing import AudioPreprocessor, RecentLog
 
 SHIPPED_FLAGS = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
@@ -39,7 +39,8 @@ class MultiStreamDetector:
     def __init__(self, model, n_streams: int, sample_rate: int = 16000, window_duration: float = 1.0,
                  hop_duration: float = 0.25, confidence_threshold: float = 0.5, smoothing_window: int = 3,
                  debounce_seconds: float = 0.5, clock: Optional[Callable[[], float]] = None,
-                 max_chunk: int = 16000, preprocessor: Optional[AudioPreprocessor] = None, use_graphs: bool = True):
+                 max_chunk: int = 16000, preprocessor: Optional[AudioPreprocessor] = None, use_graphs: bool = True,
+                 prob_history: int = 1024):
         if not torch.cuda.is_available():
             raise RuntimeError("cough_detector_amd needs an AMD GPU (gfx950); there is no CPU fallback")
         self.dev = torch.device("cuda", torch.cuda.current_device())
@@ -50,6 +51,9 @@ class MultiStreamDetector:
         self.n_streams = n_streams
         self.window = int(sample_rate * window_duration)
         self.hop = int(sample_rate * hop_duration)
+        if self.hop < 1:
+            raise ValueError(f"MultiStreamDetector: hop_duration={hop_duration} gives a hop of {self.hop} samples; it must be "
+                             "at least one sample")
         self.max_chunk = max_chunk
         self.ring_len = self.window + max_chunk + self.hop
         self.rings = torch.zeros((n_streams, self.ring_len), dtype=torch.float32, device=self.dev)
@@ -60,7 +64,9 @@ class MultiStreamDetector:
         self.history = [deque(maxlen=smoothing_window) for _ in range(n_streams)]
         self.last_detection = np.zeros(n_streams, dtype=np.float64)
         self.clock = clock or (lambda: __import__("time").time())
-        self.window_probs: List[List[float]] = [[] for _ in range(n_streams)]
+        # the most recent per-window probabilities of every stream (diagnostics; bounded) and the number of windows scored
+        self.window_probs: List[List[float]] = [RecentLog(prob_history) for _ in range(n_streams)]
+        self.windows_seen = 0
         self._lib = _lib.load()
         self.use_graphs = use_graphs
         self._g = None            # captured steady state: dict(length, buffers, graphs)
@@ -174,6 +180,7 @@ class MultiStreamDetector:
                 continue
             conf = float(p[k])
             self.window_probs[s].append(conf)
+            self.windows_seen += 1
             h = self.history[s]
             h.append(conf)
             # np.mean of the reference (inference.py:223) adds < 8 float64 values left to right, as sum() does;

@@ -28,8 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported
+ * (tests/test_host_logic.py compares `nm -D` of the built library with this list). */
+#pragma GCC visibility push(default)
 
-#define COUGH_AMD_ABI_VERSION 4
+#define COUGH_AMD_ABI_VERSION 5
 
 #define COUGH_OK 0
 #define COUGH_EINVAL 1        /* bad argument (NULL, negative size, misaligned pointer) */
@@ -108,6 +111,17 @@ size_t cough_featurizer_workspace_bytes(const cough_featurizer* f, int n_clips);
 int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat,
                        int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Waveforms of ANY length through one handle.  The reference's extract_features never checks the length of its input
+ * (/root/reference/src/preprocessing.py:432-489: T = 1 + N / hop_length frames for whatever N arrives), and none of a
+ * featuriser's tables depends on it: n_samples is a launch parameter.  n_samples = 0 or = segment_samples is exactly
+ * cough_featurize_ws / cough_featurizer_workspace_bytes / cough_featurizer_num_frames; any other length (> n_fft / 2, the
+ * reflect padding of torch.stft) runs on the generic kernel chain and needs cough_featurizer_workspace_bytes_for() bytes.
+ * d_feat: [n_clips][num_features][cough_featurizer_num_frames_for(f, n_samples)]. */
+int cough_featurizer_num_frames_for(const cough_featurizer* f, int n_samples);
+size_t cough_featurizer_workspace_bytes_for(const cough_featurizer* f, int n_samples, int n_clips);
+int cough_featurize_any(const cough_featurizer* f, const float* d_wav, long long wav_stride, int n_samples, float* d_feat,
+                        int n_clips, int flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Stand-alone STFT: T.Spectrogram(n_fft, win_length, hop_length, power=2.0) of
  * /root/reference/src/preprocessing.py:131-136 (the "STFT stage" on its own; cough_featurize never
  * materialises it) at the featuriser's geometry.  d_spec: [n_clips][n_fft/2+1][num_frames] float32
@@ -119,6 +133,9 @@ int cough_featurize_ws(const cough_featurizer* f, const float* d_wav, long long 
 #define COUGH_SPEC_FULL_WINDOW 2
 int cough_spectrogram(const cough_featurizer* f, const float* d_wav, long long wav_stride,
                       float* d_spec, int n_clips, int flags, void* stream);
+/* ... of waveforms of n_samples each (0 = segment_samples): d_spec [n_clips][n_fft/2+1][num_frames_for(n_samples)] */
+int cough_spectrogram_any(const cough_featurizer* f, const float* d_wav, long long wav_stride, int n_samples,
+                          float* d_spec, int n_clips, int flags, void* stream);
 
 /* The three helper methods of AudioPreprocessor a caller may use on their own (extract_features fuses them):
  *   cough_pre_emphasis   apply_pre_emphasis (/root/reference/src/preprocessing.py:214-240): y[0] = x[0],
@@ -317,6 +334,7 @@ int cough_window_gather(const float* d_rings, int ring_len, const int* d_stream_
                         const long long* d_start_pos, int n_windows, int window_len,
                         float* d_out, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,45 @@ def test_unknown_env_dtype_is_rejected_and_the_old_name_is_mapped(monkeypatch, c
     monkeypatch.setenv("COUGH_BENCH_DTYPE", "fp8")
     with pytest.raises(SystemExit):
         bench.parse_args([])
+
+
+def test_live_pmc_never_nests_profilers_and_scrubs_the_child_environment(monkeypatch):
+    """under `rocprofv3 ... -- python bench.py` the process inherits the profiler's LD_PRELOAD /
+    ROCP_TOOL_LIBRARIES / ROCPROF_* variables; starting `rocprofv3` again from there would initialise the GPU in the launcher and
+    then exec.  live_pmc must (a) start nothing when it already runs under a profiler and say why, (b) otherwise hand its
+    children an environment without any profiler or torchrun variable."""
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            started.append((cmd, kw))
+
+        def wait(self, timeout=None):
+            return 1                                  # "rocprofv3 failed": the fallback path, with the reason recorded
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(bench.shutil if hasattr(bench, "shutil") else __import__("shutil"), "which", lambda name: "/usr/bin/" + name)
+    args = bench.parse_args(["--steps", "3"])
+    for k in list(os.environ):
+        if k.startswith(("ROCP_", "ROCPROF_", "ROCPROFILER_")) or k in ("LD_PRELOAD", "HSA_TOOLS_LIB"):
+            monkeypatch.delenv(k)
+    # (a) under a profiler: nothing is started
+    for var, val in (("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("ROCP_TOOL_LIBRARIES", "librocprofiler-sdk-tool.so"),
+                     ("ROCPROF_COUNTER_COLLECTION", "1")):
+        monkeypatch.setenv(var, val)
+        assert bench.under_profiler()
+        res, why = bench.live_pmc(args)
+        assert res is None and "under a profiler" in why and started == []
+        monkeypatch.delenv(var)
+    assert not bench.under_profiler()
+    # (b) clean run: one child per pass would start; its environment is scrubbed
+    monkeypatch.setenv("LD_PRELOAD", "/some/unrelated.so")           # not a profiler, still never handed to a profiled child
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    res, why = bench.live_pmc(args)
+    assert res is None and "exit code 1" in why and len(started) == 1   # first pass failed -> fallback, reason kept
+    cmd, kw = started[0]
+    assert cmd[0] == "rocprofv3" and "--pmc" in cmd and "--no-live-pmc" in cmd and cmd[cmd.index("--") + 1] == sys.executable
+    assert not any(t in cmd for t in ("--kernel-trace", "--sys-trace", "--hip-trace", "-s", "-r"))   # counters only
+    env = kw["env"]
+    assert "LD_PRELOAD" not in env and "WORLD_SIZE" not in env
+    assert not any(k.startswith(("ROCP_", "ROCPROF_")) for k in env) and env["TMPDIR"] == "/tmp"

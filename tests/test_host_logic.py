@@ -24,8 +24,21 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cough_amd_abi_version() == 4
+    assert lib.cough_amd_abi_version() == 5
     assert lib.cough_amd_arch() == b"gfx950"
+
+
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """-fvisibility=hidden + a linker version script -- `nm -D` of the built library lists the entry points of
+    include/cough_amd.h and nothing else (no C++-mangled internals, no std:: instantiations)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    header = open(os.path.join(ROOT, "include", "cough_amd.h")).read()
+    declared = set(re.findall(r"\b(cough_[a-z_0-9]+)\s*\(", header))
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_ctypes_structs_match_header_layout():
@@ -304,3 +317,20 @@ def test_featuriser_refuses_non_tensor_and_integer_waveforms():
         pre.extract_features(np.zeros((1, 16000), np.float32))
     with pytest.raises(TypeError, match="floating-point"):
         pre.extract_features(torch.zeros(1, 16000, dtype=torch.int16))     # torch.stft refuses integer input as well
+
+
+def test_probability_logs_are_bounded_and_a_zero_hop_is_refused():
+    """a detector that runs for months must not grow (one float per window forever), and
+    hop_duration <= 0 is an endless loop in the reference's add_audio -- a ValueError here."""
+    log = preprocessing.RecentLog(5)
+    for i in range(1000):
+        log.append(i)
+        assert len(log) < 10
+    assert list(log)[-5:] == [995, 996, 997, 998, 999] and log[-1] == 999 and log[-3:] == [997, 998, 999]
+    with pytest.raises(ValueError):
+        preprocessing.RecentLog(0)
+    for hop in (0.0, -0.25, 1e-6):
+        with pytest.raises(ValueError, match="hop_duration"):
+            cda.RealtimePreprocessor(window_duration=1.0, hop_duration=hop, **SHIPPED)
+    rt = cda.RealtimePreprocessor(window_duration=1.0, hop_duration=1.0 / 16000, **SHIPPED)
+    assert rt.hop_samples == 1

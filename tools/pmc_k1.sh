@@ -5,6 +5,7 @@ set -u
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/${1:-pmc_k1}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export COUGH_BENCH_LIVE_PMC=0   # bench.py must not start rocprofv3 children of its own under this profiler
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 run() {  # name, counters...
   name=$1; shift

@@ -7,6 +7,7 @@ mkdir -p "$OUT"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 SCRIPT=$REPO/$1; shift
 cd /tmp && export TMPDIR=/tmp
+export COUGH_BENCH_LIVE_PMC=0   # bench.py must not start rocprofv3 children of its own under this profiler
 run() {  # name, counters...
   name=$1; shift
   timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- \

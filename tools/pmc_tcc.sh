@@ -7,6 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 SCRIPT=$REPO/$1; shift
 ARGS=("$@")
 cd /tmp && export TMPDIR=/tmp
+export COUGH_BENCH_LIVE_PMC=0   # bench.py must not start rocprofv3 children of its own under this profiler
 run() { name=$1; shift
   timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$SCRIPT" "${ARGS[@]}" > "$OUT/$name.log" 2>&1; }
 run ea1 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum

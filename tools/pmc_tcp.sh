@@ -9,6 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 SCRIPT=$REPO/$1; shift
 ARGS=("$@")
 cd /tmp && export TMPDIR=/tmp
+export COUGH_BENCH_LIVE_PMC=0   # bench.py must not start rocprofv3 children of its own under this profiler
 run() { name=$1; shift
   timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$SCRIPT" "${ARGS[@]}" > "$OUT/$name.log" 2>&1; }
 run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum

@@ -4,6 +4,7 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 SCRIPT=$REPO/$1; shift
 mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
+export COUGH_BENCH_LIVE_PMC=0   # bench.py must not start rocprofv3 children of its own under this profiler
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o p -- python3 "$SCRIPT" "$@" > "$OUT/run.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
