@@ -112,3 +112,32 @@ def test_live_pmc_never_nests_profilers_and_scrubs_the_child_environment(monkeyp
     env = kw["env"]
     assert "LD_PRELOAD" not in env and "WORLD_SIZE" not in env
     assert not any(k.startswith(("ROCP_", "ROCPROF_")) for k in env) and env["TMPDIR"] == "/tmp"
+
+
+def test_streaming_bench_parent_command_and_single_aggregated_line():
+    """configs[4] under torchrun must yield ONE JSON line for the job -- global latency percentiles over every
+    rank's samples, aggregate windows/s over the slowest rank's wall time, the per-rank records -- not one line per rank."""
+    import json
+    import bench_streaming as bs
+    argv = ["--gpus", "8", "--streams", "64", "--seconds", "5"]
+    cmd = bs.build_launch_cmd(argv, 8, 29611)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-len(argv):] == argv
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench_streaming.py")
+    args = bs.parse_args(argv)
+    lat = [[0.10, 0.20, 0.30], [0.40, 5.0], []]                         # rank 2 served no window
+    recs = [{"rank": r, "device": r, "streams": s, "ticks": 50, "ticks_with_windows": len(l), "windows": w, "wall_s": t}
+            for r, (l, s, w, t) in enumerate(zip(lat, (22, 21, 21), (66, 42, 0), (1.0, 2.0, 0.5)))]
+    line = bs.aggregate(lat, recs, args, "gloo", 3)
+    json.dumps(line)                                                     # serialisable as it stands
+    assert line["n_gpus"] == line["rccl_world"] == 3 and line["config"]["streams"] == 64
+    assert line["latency_ms_max"] == 5.0 and line["latency_ms_p50"] == 0.3 and line["value"] == 0.3 and line["unit"] == "ms"
+    assert line["windows"] == 108 and line["sustained_windows_per_s"] == 54.0      # 108 windows / the slowest rank's 2.0 s
+    assert line["higher_is_better"] is False and len(line["ranks"]) == 3
+    assert line["ranks"][2]["latency_ms_p50"] is None and line["ranks"][0]["latency_ms_max"] == 0.3
+    # explicit evidence of too few devices: the parent refuses without touching the GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_streaming.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and p.stdout == "" and "only 1 device(s) visible" in p.stderr

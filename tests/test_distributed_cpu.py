@@ -150,3 +150,30 @@ def _records_worker(rank, world, port):
 def test_rank_records_are_gathered_in_rank_order_gloo(world):
     """bench.py's N > 1 line: every rank's own device / clock / kernel times / exchange counters."""
     mp.spawn(_records_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _latency_worker(rank, world, port):
+    """bench_streaming.py's end-of-run exchange: ragged per-rank latency samples (a rank may have none) + records."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_streaming as bs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = [0.1 * (rank + 1) + 0.01 * i for i in range(5 - 2 * rank)] if rank < 2 else []     # 5, 3, 0 samples
+        rec = {"rank": rank, "device": 0, "streams": 22 - rank, "ticks": 50, "ticks_with_windows": len(mine),
+               "windows": 10 * len(mine), "wall_s": 1.0 + rank}
+        lats, recs = bs.gather_latencies(mine, rec, torch.device("cpu"))
+        assert [len(l) for l in lats] == [5, 3, 0][:world] and [r["rank"] for r in recs] == list(range(world))
+        assert lats[rank] == pytest.approx(mine) and recs[rank]["streams"] == 22 - rank
+        line = bs.aggregate(lats, recs, bs.parse_args(["--streams", "64"]), "gloo", world)
+        assert line["windows"] == sum(10 * n for n in [5, 3, 0][:world]) and len(line["ranks"]) == world
+        assert line["sustained_windows_per_s"] == round(line["windows"] / float(world), 1)          # slowest rank: wall = world s
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_streaming_bench_gathers_ragged_latency_samples_gloo(world):
+    mp.spawn(_latency_worker, args=(world, _free_port()), nprocs=world, join=True)
