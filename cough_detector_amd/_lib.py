@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.s
 
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1
+PATH_GENERIC, PATH_TUNED, PATH_TUNED_FULLBAND = 0, 1, 2
 SPEC_MAGNITUDE, SPEC_FULL_WINDOW = 1, 2
 DTYPE_FP32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 3
 DTYPES = {"fp32": DTYPE_FP32, "bf16_approx": DTYPE_BF16, "bf16x3": DTYPE_BF16X3}
@@ -37,7 +38,7 @@ def normalize_dtype(compute_dtype: str, allowed) -> str:
 SYMBOLS = (
     "cough_amd_abi_version", "cough_amd_arch", "cough_amd_last_error",
     "cough_featurizer_create", "cough_featurizer_destroy", "cough_featurizer_num_features",
-    "cough_featurizer_num_frames", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
+    "cough_featurizer_num_frames", "cough_featurizer_path", "cough_featurize", "cough_featurizer_workspace_bytes", "cough_featurize_ws",
     "cough_spectrogram", "cough_featurizer_num_frames_for", "cough_featurizer_workspace_bytes_for", "cough_featurize_any",
     "cough_spectrogram_any",
     "cough_resnet_create", "cough_resnet_create_ex", "cough_resnet_destroy", "cough_resnet_workspace_bytes",
@@ -113,6 +114,7 @@ def load() -> C.CDLL:
         lib.cough_featurizer_destroy.restype = None
         lib.cough_featurizer_num_features.argtypes = [vp]
         lib.cough_featurizer_num_frames.argtypes = [vp]
+        lib.cough_featurizer_path.argtypes = [vp]
         lib.cough_featurize.argtypes = [vp, vp, ll, vp, i, i, vp]
         lib.cough_spectrogram.argtypes = [vp, vp, ll, vp, i, i, vp]
         lib.cough_featurizer_workspace_bytes.argtypes = [vp, i]

@@ -134,20 +134,54 @@ static_assert(ST_IMG <= LDS_MEL, "the bf16 feature image aliases the dB buffer")
 constexpr size_t ST_X3_OFF = LDS_TOTAL - 2 * ST_IMG;
 static_assert(ST_X3_OFF % 16 == 0 && ST_IMG % 4 == 0 && ST_X3_OFF >= size_t(NMF) * 4, "hi / lo images vs the MFCC buffer");
 
+// kernel argument of the FULL instantiations: device pointers into the featuriser's full-band blob
+struct FullBank {
+    int n_mels, n_mfcc, n_taps;
+    int maxw[2];             // widest band of bands 0..63 / 64..127 (taps)
+    int cph, cph_pad, cw;    // MFCCs of the first thread half (ceil(n_mfcc / 2)); table rows per half (whole chunks); chunk width 4..7
+    const int *lo, *hi, *off;   // [n_mels] first bin, end bin, offset of the band's taps in w
+    const float* w;          // CSR taps, times 1/4 (the spectrum is formed as 2X)
+    const float* dct;        // [2][cph_pad / cw chunks][n_mels][8] DCT-II (ortho): the cw coefficients of a chunk per mel band,
+                             // zero-padded to 8 floats
+};
+constexpr size_t full_mel_bytes(int n_mels) { return (size_t(n_mels) * NFRAMES * 4 + 15) & ~size_t(15); }
+// FULL: a wave's transpose scratch interleaves its four frames -- element (row k, frame f, column n) at 65 k + 16 f + n, the
+// layout of the stand-alone STFT kernel (spectrogram.hip) -- in 1040 floats instead of 4 x 272; afterwards it holds the four
+// frames' power rows of 257 (+ 1 padding) bins at a pitch of 260.  768 bytes less per workgroup: an 80-band bank then still fits
+// three workgroups per CU (the hardware grants three up to 53 760 B each -- 1280-byte granules, tools/micro/lds_occupancy.hip)
+constexpr int FX_ROW = FPW * 16 + 1, FX_WAVE = 16 * FX_ROW, FX_PROW = 260;
+static_assert(FPW * FX_PROW <= FX_WAVE && FX_PROW >= NFFT / 2 + 2 && FX_PROW % 2 == 0, "four power rows replace the transposes");
+constexpr size_t LDS_XCH_FULL = size_t(WAVES) * FX_WAVE * 4;   // 16640
+constexpr int FULL_MAX_MFCC = int(LDS_XCH_FULL / (size_t(2) * NFRAMES * 4));   // 20: MFCC + delta buffers alias the scratch
+constexpr size_t full_lds_bytes(int n_mels, int n_taps) {
+    return LDS_XCH_FULL + full_mel_bytes(n_mels) + LDS_RED + LDS_TW + ((size_t(n_taps) * 4 + 15) & ~size_t(15));
+}
+
 // PRE_EMPH: pre-emphasis is a separate instantiation (it never costs the shipped path registers).
 // STEM: the classifier's stem (conv7x7 s2 + BN + ReLU + maxpool, model.py:227-232) runs at the end of the kernel on
 // the matrix cores out of a bf16 copy of the feature image in LDS; `out` may then be nullptr.  1: plain bf16 operands,
 // bf16 output; 2: split-bf16 (image and weights as hi + lo, hi*hi + lo*hi + hi*lo per k-step), f32 output.
-template <bool PRE_EMPH, int STEM>
+// FULL: the full-band instantiations -- the same one-launch kernel for ANY filterbank at the shipped STFT geometry (f_max up to the
+// Nyquist bin, bands of any width, 2..128 mel bands, up to 20 MFCCs): all 257 bins are formed (X[k] and X[256 - k] from the same
+// butterfly, as the stand-alone STFT does), the filterbank is a CSR table in LDS (lane = band, a band's taps in ascending bin
+// order), n_mels / n_mfcc are run-time sizes and the dB buffer is sized by them.  The shipped instantiations (FULL = false) keep
+// their <= 8 register taps per band below bin 128 and compile-time sizes.
+template <bool PRE_EMPH, int STEM, bool FULL = false>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
-    1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem) {
+    1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem, FullBank fbk,
+    const float* __restrict__ full_dct /* = fbk.dct: read-only for the kernel's lifetime, so its wave-uniform loads are scalar */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nmel = FULL ? fbk.n_mels : NMEL, nmfcc = FULL ? fbk.n_mfcc : NMFCC, nmf = nmfcc * NFRAMES;
+    const size_t lds_mel = FULL ? full_mel_bytes(nmel) : LDS_MEL;
+    constexpr size_t lds_xch = FULL ? LDS_XCH_FULL : LDS_XCH;
     float* xs = reinterpret_cast<float*>(smem);
-    float* melbuf = reinterpret_cast<float*>(smem + LDS_XCH);
-    float* red = reinterpret_cast<float*>(smem + LDS_XCH + LDS_MEL);
-    float2* twl = reinterpret_cast<float2*>(smem + LDS_XCH + LDS_MEL + LDS_RED);   // [16][XROW]
+    float* melbuf = reinterpret_cast<float*>(smem + lds_xch);
+    float* red = reinterpret_cast<float*>(smem + lds_xch + lds_mel);
+    float2* twl = reinterpret_cast<float2*>(smem + lds_xch + lds_mel + LDS_RED);   // [16][XROW]
+    // FULL: the taps of the CSR filterbank behind the twiddle table (a band's first bin / width / tap offset live in registers)
+    float* c_w = reinterpret_cast<float*>(smem + lds_xch + lds_mel + LDS_RED + LDS_TW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long clip = blockIdx.x;
@@ -162,6 +196,29 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // ---------------- P1: STFT power -> mel -> dB ----------------
     const int j = lane & 15, fsub = lane >> 4;
     twl[(tid >> 4) * XROW + (tid & 15)] = tb->tw256[tid >> 4][tid & 15];   // 256 threads = 16 x 16 entries
+    // FULL: lane = band.  Pass 0 takes bands 0..63 with the wave's four frames per lane; the LAST pass of a bank with more than 64
+    // bands maps its r = n_mels - 64 bands as (band, frames): all four frames per lane for r > 32, two for r > 16, one otherwise --
+    // so 80 bands do not leave 48 of 64 lanes idle through the widest bands of the bank
+    int b_lo[2] = {0, 0}, b_w[2] = {0, 0}, b_band[2] = {0, 0};
+    const float* b_taps[2] = {c_w, c_w};
+    int fpl1 = FPW;   // frames per lane in pass 1
+    if constexpr (FULL) {
+        for (int i = tid; i < fbk.n_taps; i += THREADS) c_w[i] = fbk.w[i];
+        const int r = nmel - 64;
+        fpl1 = r > 32 ? 4 : r > 16 ? 2 : 1;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int mb = ps == 0 ? lane : 64 + (fpl1 == 4 ? lane : fpl1 == 2 ? (lane & 31) : (lane & 15));
+            if (mb < nmel) {
+                b_band[ps] = mb;
+                b_lo[ps] = fbk.lo[mb];
+                b_w[ps] = fbk.hi[mb] - b_lo[ps];
+                b_taps[ps] = c_w + fbk.off[mb];
+            } else {
+                b_band[ps] = -1;   // idle lane
+            }
+        }
+    }
     __syncthreads();
     const float2* tw_row = twl + j * XROW;   // row pitch 17 float2: the 16 lanes of a frame hit 16 distinct banks
     const float2 tw_j = tb->tw512[j];   // W512^j; W512^(j+16*k2) = W512^j * W32^k2
@@ -170,7 +227,11 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     for (int q = 0; q < MAXW; ++q) mw[q] = tb->mel_w[lane][q];
     const int mstart = tb->mel_start[lane];
 
-    float* myx = xs + (wave * FPW + fsub) * XFRAME;
+    float* myx = xs + (wave * FPW + fsub) * XFRAME;                 // shipped: the frame's own 16 x 17 scratch
+    float* myw = xs + wave * FX_WAVE;                               // FULL: the wave's interleaved scratch
+    float* fxw = myw + 16 * fsub + j;                               //   transpose write base: row k1 at fxw[k1 * FX_ROW]
+    const float* fxr = myw + FX_ROW * j + 16 * fsub;                //   transpose read base: column n2 at fxr[n2]
+    float* prow = myw + FX_PROW * fsub;                             //   afterwards: this frame's power row
     float run_max = -INFINITY;   // max raw dB seen by this lane
     float peak = 0.f;            // max |sample| seen by this lane
     float chk = 0.f;             // stays 0 while every mel power of this lane is finite, NaN otherwise (acc * 0)
@@ -271,16 +332,16 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
         float2 z[16];
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].x;
+        for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].x;
         wave_lds_fence();
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) z[n2].x = myx[j * XROW + n2];
+        for (int n2 = 0; n2 < 16; ++n2) z[n2].x = FULL ? fxr[n2] : myx[j * XROW + n2];
         wave_lds_fence();
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) myx[k1 * XROW + j] = a[k1].y;
+        for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].y;
         wave_lds_fence();
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) z[n2].y = myx[j * XROW + n2];
+        for (int n2 = 0; n2 < 16; ++n2) z[n2].y = FULL ? fxr[n2] : myx[j * XROW + n2];
         K1_MARK("PHASE P1 radix-16 #2");
         dft16(z);   // z[k2] = Z[j + 16*k2]
         K1_MARK("PHASE P1 real-input split + |X|^2 -> LDS");
@@ -293,6 +354,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
         }
         wave_lds_fence();
+        if constexpr (!FULL) {
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
             const float2 zk = z[k2];
@@ -325,6 +387,77 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 run_max = fmaxf(run_max, db);
                 chk = fmaf(acc, 0.f, chk);   // NaN / Inf power (a non-finite sample under the frame, f32 overflow) -> NaN, sticky
             }
+        }
+        } else {
+        // all 257 bins: 2X[k] = 2E + W^k 2O and 2X[256 - k] = conj(2E - W^k 2O) from the same butterfly (as spectrogram.hip);
+        // the four power rows of the wave's frames replace its transpose scratch
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const float2 zk = z[k2];
+            const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+            const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+            const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+            const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+            const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+            const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+            const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+            prow[j + 16 * k2] = ar * ar + ai * ai;
+            prow[NFFT / 2 - (j + 16 * k2)] = br * br + bi * bi;
+        }
+        if (j == 0) prow[NFFT / 4] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // X[128] = conj Z[128]
+        wave_lds_fence();
+        K1_MARK("PHASE P1 CSR mel + log2 -> LDS");
+        // CSR mel: lane = band (64 bands per pass), the wave's 4 frames share every tap read; a band's taps run in ascending
+        // bin order up to the widest band of the pass (wave-uniform bound, narrower bands idle)
+        auto mel_pass = [&](auto fpl_tag, int ps) {
+            constexpr int FPL = decltype(fpl_tag)::value;   // frames per lane: 4, 2 or 1
+            const int f0 = FPL == 4 ? 0 : FPL == 2 ? 2 * (lane >> 5) : (lane >> 4);
+            const int mb = b_band[ps], wdt = mb >= 0 ? b_w[ps] : 0;
+            const float* wm = b_taps[ps];
+            const float* p0 = myw + f0 * FX_PROW + b_lo[ps];
+            float acc[FPL];
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) acc[f] = 0.f;
+            // Branch-free, two PAIRS of bins per step, every access an aligned 8-byte LDS read: a band's taps start at an even bin
+            // and have an even count (zero taps as padding, built at create time), so the taps and the four frames' powers of a bin
+            // pair are one ds_read_b64 each and the reads of a step are all in flight together.  (One tap per iteration behind a
+            // divergent branch serialised the loop on the LDS latency -- 19 round trips for the widest band of the 64-band / 8 kHz
+            // bank; 4-byte reads with clamped indices cost 100 LDS instructions per four-frame group.)  A lane past its band's end
+            // re-reads the band's last pair with weight 0: no read leaves the band.
+            const int wmax = fbk.maxw[ps];   // a multiple of 4
+            const int lastp = wdt > 2 ? wdt - 2 : 0;
+            for (int k0 = 0; k0 < wmax; k0 += 4) {
+                float2 w[2], pw[2][FPL];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = k0 + 2 * u, kk = k < lastp ? k : lastp;
+                    w[u] = *reinterpret_cast<const float2*>(wm + kk);
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) pw[u][f] = *reinterpret_cast<const float2*>(p0 + f * FX_PROW + kk);
+                    if (k >= wdt) w[u] = make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) acc[f] = fmaf(w[u].y, pw[u][f].y, fmaf(w[u].x, pw[u][f].x, acc[f]));
+            }
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const int tf = FPW * g + f0 + f;
+                if (mb >= 0 && tf < NFRAMES) {
+                    const float db = 3.01029995663981195f * __log2f(acc[f]);   // as above
+                    melbuf[mb * NFRAMES + tf] = db;
+                    run_max = fmaxf(run_max, db);
+                    chk = fmaf(acc[f], 0.f, chk);
+                }
+            }
+        };
+        mel_pass(std::integral_constant<int, 4>{}, 0);
+        if (nmel > 64) {   // workgroup-uniform
+            if (fpl1 == 4) mel_pass(std::integral_constant<int, 4>{}, 1);
+            else if (fpl1 == 2) mel_pass(std::integral_constant<int, 2>{}, 1);
+            else mel_pass(std::integral_constant<int, 1>{}, 1);
+        }
         }
         wave_lds_fence();
     }
@@ -362,7 +495,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // (preprocessing.py:405-410, :428; normalize() leaves a clip with a NaN maximum alone, :209-212)
     if (raw_max == INFINITY) {   // workgroup-uniform
         const float nanv = __builtin_nanf("");
-        const int rows = NMEL + (delta_delta == 2 ? 0 : (delta_delta == 1 ? 3 : 2) * NMFCC);
+        const int rows = nmel + (delta_delta == 2 ? 0 : (delta_delta == 1 ? 3 : 2) * nmfcc);
         if (wr)
             for (int i = tid; i < rows * NFRAMES; i += THREADS) o[i] = nanv;
         if constexpr (STEM != 0)
@@ -414,7 +547,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     }
     K1_MARK("ENDSKIP");
     K1_MARK("PHASE P2 floor + mel rows store");
-    for (int i2 = tid; i2 < NMEL * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores
+    for (int i2 = tid; i2 < nmel * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores (n_mels is even)
         float2 d = reinterpret_cast<float2*>(melbuf)[i2];
         d.x = fmaxf(fmaxf(d.x - shift, -100.0f), floor_db);
         d.y = fmaxf(fmaxf(d.y - shift, -100.0f), floor_db);
@@ -430,9 +563,55 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     K1_MARK("PHASE P2 DCT 13x64");
     // DCT: thread = (frame t, coefficient half); coefficients are wave-uniform -> scalar loads
     float* mf = xs;              // [13][101] z-scored MFCC
-    float* dl = mf + NMF;        // delta (needed in LDS only for delta-delta)
+    float* dl = mf + nmf;        // delta (needed in LDS only for delta-delta)
     const int tt = tid & 127;
     const int chalf = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: c 0..6; waves 2,3: c 7..12
+    if constexpr (FULL) {
+        // run-time n_mels / n_mfcc: the half's coefficients in chunks of fbk.cw (the table is [half][cph_pad][n_mels] with zero rows
+        // up to whole chunks, so the loop stays free of branches and its coefficients scalar loads); raw MFCCs go to LDS, the
+        // z-score follows out of LDS
+        const int cph = fbk.cph, nch = chalf ? nmfcc - cph : cph, cbase = chalf * cph;
+        auto dct_chunks = [&](auto cw_tag) {
+            constexpr int CW = decltype(cw_tag)::value;   // coefficients per chunk
+            for (int cq = 0; cq < nch; cq += CW) {
+                float acc[CW];
+#pragma unroll
+                for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.f;
+                if (tt < NFRAMES) {
+                    // the chunk's coefficients of one mel band are 8 consecutive floats: one s_load_dwordx8 per band (rows at a
+                    // run-time stride of n_mels made every coefficient a scalar load of its own: 3x the shipped DCT phase)
+                    const float* drow = full_dct + (size_t(chalf) * fbk.cph_pad + cq) / CW * size_t(nmel) * 8;
+#pragma unroll 8
+                    for (int m = 0; m < nmel; ++m) {
+                        const float v = melbuf[m * NFRAMES + tt];
+#pragma unroll
+                        for (int cc = 0; cc < CW; ++cc) acc[cc] = fmaf(drow[m * 8 + cc], v, acc[cc]);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc)
+                        if (cq + cc < nch) mf[(cbase + cq + cc) * NFRAMES + tt] = acc[cc];
+                }
+            }
+        };
+        // the chunk width that wastes the fewest zero rows: 7 for up to seven coefficients per half (13 MFCCs), 5 for ten (20), ...
+        if (fbk.cw == 7) dct_chunks(std::integral_constant<int, 7>{});
+        else if (fbk.cw == 6) dct_chunks(std::integral_constant<int, 6>{});
+        else if (fbk.cw == 5) dct_chunks(std::integral_constant<int, 5>{});
+        else dct_chunks(std::integral_constant<int, 4>{});
+        __syncthreads();
+        float ls = 0.f;
+        for (int i = tid; i < nmf; i += THREADS) ls += mf[i];
+        const float mean = block_sum(ls, red, tid) / float(nmf);
+        float lq = 0.f;
+        for (int i = tid; i < nmf; i += THREADS) {
+            const float d = mf[i] - mean;
+            lq += d * d;
+        }
+        const float sd = sqrtf(block_sum(lq, red, tid) / float(nmf - 1));   // torch.std: unbiased
+        const float rdenom = 1.0f / (sd + 1e-8f);                            // (x - mean) / (std + 1e-8), :428
+        K1_STAMP(5);   // DCT + mean + std done
+        for (int i = tid; i < nmf; i += THREADS) mf[i] = (mf[i] - mean) * rdenom;
+    } else {
     const int c0 = chalf * 7, nc = chalf ? 6 : 7;
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (tt < NFRAMES) {
@@ -465,6 +644,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 #pragma unroll
         for (int cc = 0; cc < 7; ++cc)
             if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
+    }
     }
     __syncthreads();
     K1_MARK("PHASE P2 feature image (stem) + MFCC / delta rows");
@@ -500,9 +680,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             }
         }
     }
-    float* o_mfcc = o + NMEL * NFRAMES;
-    float* o_delta = o_mfcc + NMF;
-    for (int item = tid; item < NMF; item += THREADS) {
+    float* o_mfcc = o + nmel * NFRAMES;
+    float* o_delta = o_mfcc + nmf;
+    for (int item = tid; item < nmf; item += THREADS) {
         const int c = item / NFRAMES, t = item - c * NFRAMES;
         const float* row = mf + c * NFRAMES;
         const float d = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;   // :353-355
@@ -519,8 +699,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     K1_STAMP(6);
     if (delta_delta == 1) {
         __syncthreads();
-        float* o_dd = o_delta + NMF;
-        for (int item = tid; item < NMF; item += THREADS) {
+        float* o_dd = o_delta + nmf;
+        for (int item = tid; item < nmf; item += THREADS) {
             const int c = item / NFRAMES, t = item - c * NFRAMES;
             const float* row = dl + c * NFRAMES;
             o_dd[item] = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
@@ -627,7 +807,11 @@ struct cough_featurizer {
     int nbase;           // rows the featurise kernel writes (mel [+ MFCC, delta, delta-delta])
     cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
     int n_cus;           // compute units of the device the featuriser was created on
-    bool tuned;          // the one-launch kernel serves the constructor's segment length
+    int kind;            // the one-launch kernel that serves the constructor's segment length: 0 none (generic chain), 1 the
+                         // shipped sparse-filterbank instantiations, 2 the full-band ones (any filterbank, run-time n_mels / n_mfcc)
+    char* d_full;        // kind 2: CSR filterbank + DCT rows (one blob)
+    cough::FullBank full;
+    size_t full_lds;     // kind 2: dynamic LDS of a workgroup
     cough::GenFeat* gen; // the generic kernel chain's tables (featurize_generic.hip): every geometry the tuned kernel does not
                          // cover, and -- for every featuriser -- waveforms of any other length (extract_features of any N)
 };
@@ -636,33 +820,81 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                                        const float* window, const float* mel_fb, const float* dct) {
     using namespace cough;
     COUGH_REQUIRE(out && cfg && window && mel_fb && dct, COUGH_EINVAL, "cough_featurizer_create: NULL argument");
-    // The tuned one-kernel path serves the shipped geometry with a filterbank of <= 8 taps per band below bin 128 (any
-    // f_max <= sample_rate / 4); everything else at n_fft = 512 goes to the generic kernel chain (featurize_generic.hip).
-    bool tuned = cfg->sample_rate == 16000 && cfg->n_fft == NFFT && cfg->hop_length == HOP && cfg->win_length == WIN &&
-                 cfg->n_mels == NMEL && cfg->n_mfcc == NMFCC && cfg->segment_samples == NS;
+    // The one-launch kernel serves the shipped STFT geometry (16 kHz, n_fft 512, hop 160, window 400, 1 s).  kind 1: the shipped
+    // 64-mel / 13-MFCC layout with a filterbank of <= 8 taps per band below bin 128 (any f_max <= sample_rate / 4) -- taps in
+    // registers, half the spectrum formed; kind 2: every other filterbank at that geometry (f_max up to the Nyquist bin, 2..128
+    // mel bands, up to 20 MFCCs) -- all 257 bins, CSR filterbank in LDS.  Everything else goes to the generic kernel chain
+    // (featurize_generic.hip), whose tables every featuriser carries for waveforms of other lengths.
+    const int nfreq0 = NFFT / 2 + 1;
+    const bool stft_ok = cfg->sample_rate == 16000 && cfg->n_fft == NFFT && cfg->hop_length == HOP && cfg->win_length == WIN &&
+                         cfg->segment_samples == NS;
+    bool tuned = stft_ok && cfg->n_mels == NMEL && cfg->n_mfcc == NMFCC;
     if (tuned) {
         for (int m = 0; m < NMEL && tuned; ++m) {
             int first = -1, last = -1;
-            for (int k = 0; k < NFFT / 2 + 1; ++k)
+            for (int k = 0; k < nfreq0; ++k)
                 if (mel_fb[k * NMEL + m] != 0.f) { if (first < 0) first = k; last = k; }
             if (first >= 0 && (last >= NBIN || last - first >= MAXW)) tuned = false;
         }
+    }
+    // full-band CSR tables (kind 2)
+    std::vector<int> f_lo, f_hi, f_off;
+    std::vector<float> f_taps, f_dct;
+    FullBank fb{};
+    bool full = false;
+    if (!tuned && stft_ok && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
+        (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= FULL_MAX_MFCC && cfg->n_mfcc <= cfg->n_mels)) &&
+        (!cfg->use_pcen || cfg->n_mels == NMEL)) {
+        const int nm = cfg->n_mels, nc = cfg->use_mfcc ? cfg->n_mfcc : 1;
+        fb.n_mels = nm;
+        fb.n_mfcc = nc;
+        for (int m = 0; m < nm; ++m) {
+            int first = -1, last = -1;
+            for (int k = 0; k < nfreq0; ++k)
+                if (mel_fb[k * nm + m] != 0.f) { if (first < 0) first = k; last = k; }
+            if (first < 0) { first = 0; last = -1; }   // empty band: no taps, mel power 0
+            // the kernel reads taps and powers as aligned pairs: the band starts at an even bin and has an even number of taps
+            // (zero taps as padding; bin 257 of a power row is scratch of the frame's own finite transform, times 0)
+            const int lo2 = first & ~1, hi2 = last >= first ? (last + 2) & ~1 : lo2;
+            f_lo.push_back(lo2);
+            f_hi.push_back(hi2);
+            f_off.push_back(hi2 > lo2 ? int(f_taps.size()) : 0);   // an empty band points at a valid pair (weight 0 in the kernel)
+            for (int k = lo2; k < hi2; ++k) f_taps.push_back(k >= first && k <= last ? 0.25f * mel_fb[k * nm + m] : 0.f);   // |2X|^2 / 4
+            const int w = (hi2 - lo2 + 3) / 4 * 4;   // the kernel walks a band's taps four at a time
+            if (w > fb.maxw[m >> 6]) fb.maxw[m >> 6] = w;
+        }
+        if (f_taps.size() < 2) f_taps.assign(2, 0.f);
+        fb.n_taps = int(f_taps.size());
+        fb.cph = (nc + 1) / 2;
+        const int n_chunks = (fb.cph + 6) / 7;
+        fb.cw = (fb.cph + n_chunks - 1) / n_chunks;   // 7 coefficients per half -> one chunk of 7; 10 -> two of 5; 11 -> two of 6
+        if (fb.cw < 4) fb.cw = 4;
+        fb.cph_pad = (fb.cph + fb.cw - 1) / fb.cw * fb.cw;
+        const int chunks_per_half = fb.cph_pad / fb.cw;
+        f_dct.assign(size_t(2) * chunks_per_half * nm * 8, 0.f);
+        if (cfg->use_mfcc)
+            for (int c = 0; c < nc; ++c) {
+                const int half = c >= fb.cph, r = half ? c - fb.cph : c;
+                for (int m = 0; m < nm; ++m)
+                    f_dct[((size_t(half) * chunks_per_half + r / fb.cw) * nm + m) * 8 + r % fb.cw] = dct[m * nc + c];
+            }
+        full = full_lds_bytes(nm, fb.n_taps) <= 80 * 1024;   // at least two workgroups per CU
     }
     if (cfg->use_spectral_contrast) {
         COUGH_REQUIRE(cfg->n_contrast_bands >= 1 && cfg->n_contrast_bands <= COUGH_MAX_CONTRAST_BANDS, COUGH_EUNSUPPORTED,
                       "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
         for (int i = 0; i <= cfg->n_contrast_bands; ++i) {
             const int lo = cfg->contrast_edges[i], hi = cfg->contrast_edges[i + 1];
-            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= (tuned ? 128 : 1024)),
+            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= ((tuned || full) ? 128 : 1024)),
                           COUGH_EUNSUPPORTED, "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= %d bins "
-                          "inside the spectrum", i, lo, hi, tuned ? 128 : 1024);
+                          "inside the spectrum", i, lo, hi, (tuned || full) ? 128 : 1024);
         }
     }
     std::vector<FeatTables> host(1);
     FeatTables& t = host[0];
     std::memset(&t, 0, sizeof(t));
     const double PI = 3.14159265358979323846;
-    if (tuned) {
+    if (stft_ok) {   // the STFT tables of the one-launch kernels and of the persistent STFT kernel (spectrogram.hip)
         const int left = (NFFT - WIN) / 2;
         for (int n = 0; n < WIN; ++n) t.win[left + n] = window[n];
         for (int jj = 0; jj < 16; ++jj)
@@ -674,6 +906,8 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
             const double a = -2.0 * PI * double(k) / 512.0;
             t.tw512[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
         }
+    }
+    if (tuned) {
         const int nfreq = NFFT / 2 + 1;
         for (int m = 0; m < NMEL; ++m) {
             int first = -1;
@@ -694,7 +928,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
     f->gen = gen;
-    f->tuned = tuned;
+    f->kind = tuned ? 1 : full ? 2 : 0;
+    f->d_full = nullptr;
+    f->full = fb;
+    f->full_lds = full ? full_lds_bytes(fb.n_mels, fb.n_taps) : 0;
     f->nbase = cfg->use_mfcc ? cfg->n_mels + 2 * cfg->n_mfcc + (cfg->use_delta_delta ? cfg->n_mfcc : 0) : cfg->n_mels;
     f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
     f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
@@ -709,8 +946,34 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     if (e == hipSuccess) e = hipMemcpy(f->d_win_full, hann.data(), NFFT * sizeof(float), hipMemcpyHostToDevice);
     // per-device kernel attributes (the persistent STFT kernel's 162 KB of dynamic LDS) on the creator's device
     if (e == hipSuccess && stft_prepare_device(&f->n_cus) != COUGH_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && full) {
+        // one blob: lo | hi | off (ints), taps, DCT rows; every piece 16-byte aligned
+        auto al = [](size_t v) { return (v + 15) & ~size_t(15); };
+        const size_t nm = size_t(fb.n_mels), o_hi = al(nm * 4), o_off = o_hi + al(nm * 4), o_w = o_off + al(nm * 4),
+                     o_dct = o_w + al(f_taps.size() * 4), total = o_dct + al(f_dct.size() * 4);
+        std::vector<char> blob(total, 0);
+        std::memcpy(blob.data(), f_lo.data(), nm * 4);
+        std::memcpy(blob.data() + o_hi, f_hi.data(), nm * 4);
+        std::memcpy(blob.data() + o_off, f_off.data(), nm * 4);
+        std::memcpy(blob.data() + o_w, f_taps.data(), f_taps.size() * 4);
+        std::memcpy(blob.data() + o_dct, f_dct.data(), f_dct.size() * 4);
+        e = hipMalloc(&f->d_full, total);
+        if (e == hipSuccess) e = hipMemcpy(f->d_full, blob.data(), total, hipMemcpyHostToDevice);
+        f->full.lo = reinterpret_cast<const int*>(f->d_full);
+        f->full.hi = reinterpret_cast<const int*>(f->d_full + o_hi);
+        f->full.off = reinterpret_cast<const int*>(f->d_full + o_off);
+        f->full.w = reinterpret_cast<const float*>(f->d_full + o_w);
+        f->full.dct = reinterpret_cast<const float*>(f->d_full + o_dct);
+        // more than 64 KB of dynamic LDS with many mel bands: per-device attribute, set here (not lazily at launch)
+        const void* fns[] = {reinterpret_cast<const void*>(featurize_kernel<false, 0, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 0, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true>)};
+        for (const void* fn : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    }
     if (e != hipSuccess) {
         set_error("cough_featurizer_create: %s", hipGetErrorString(e));
+        if (f->d_full) (void)hipFree(f->d_full);
         if (f->d_tables) (void)hipFree(f->d_tables);
         if (f->d_win_full) (void)hipFree(f->d_win_full);
         gen_feat_destroy(f->gen);
@@ -729,6 +992,7 @@ extern "C" __attribute__((visibility("default"))) int cough_debug_set_stamp_buff
 
 extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
     if (!f) return;
+    if (f->d_full) (void)hipFree(f->d_full);
     if (f->d_tables) (void)hipFree(f->d_tables);
     if (f->d_win_full) (void)hipFree(f->d_win_full);
     cough::gen_feat_destroy(f->gen);
@@ -736,6 +1000,7 @@ extern "C" void cough_featurizer_destroy(cough_featurizer* f) {
 }
 
 extern "C" int cough_featurizer_num_features(const cough_featurizer* f) { return f ? f->nfeat : -1; }
+extern "C" int cough_featurizer_path(const cough_featurizer* f) { return f ? f->kind : -1; }
 extern "C" int cough_featurizer_num_frames(const cough_featurizer* f) { return !f ? -1 : cough::gen_frames(f->gen, 0); }
 extern "C" int cough_featurizer_num_frames_for(const cough_featurizer* f, int n_samples) {
     return !f || n_samples < 0 ? -1 : cough::gen_frames(f->gen, n_samples);
@@ -750,9 +1015,11 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
-bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->tuned && (n_samples <= 0 || n_samples == NS); }
-bool featurizer_stem_fusable(const cough_featurizer* f) {
-    return f->tuned && f->nfeat == ST_H && f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->kind != 0 && (n_samples <= 0 || n_samples == NS); }
+bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
+    // the 90-row layout (64 mel + 13 MFCC + 13 delta); the full-band kernel is instantiated for the split-bf16 stem only
+    return (f->kind == 1 || (f->kind == 2 && x3)) && f->cfg.n_mels == NMEL && f->cfg.n_mfcc == NMFCC && f->nfeat == ST_H &&
+           f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
     if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
@@ -772,25 +1039,36 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     }
     COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                   COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
-    COUGH_REQUIRE(!stem || featurizer_stem_fusable(f), COUGH_EUNSUPPORTED,
+    COUGH_REQUIRE(!stem || featurizer_stem_fusable(f, stem->x3 != 0), COUGH_EUNSUPPORTED,
                   "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
     const int rows = (f->cfg.use_mfcc ? (f->cfg.use_delta_delta ? 1 : 0) : 2);   // kernel row selector
     const dim3 grid(n_clips), block(THREADS);
     const StemFuse none{nullptr, nullptr, nullptr, 0, nullptr};
-    if (stem && stem->x3)
+    const FullBank nofb{};
+    if (f->kind == 2) {   // full-band instantiations: CSR filterbank in LDS, run-time n_mels / n_mfcc
+        if (stem)
+            hipLaunchKernelGGL((featurize_kernel<false, 2, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, f->full, f->full.dct);
+        else if (f->cfg.use_pre_emphasis)
+            hipLaunchKernelGGL((featurize_kernel<true, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct);
+        else
+            hipLaunchKernelGGL((featurize_kernel<false, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct);
+    } else if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
     else if (stem)
         hipLaunchKernelGGL((featurize_kernel<false, 1>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
     else if (f->cfg.use_pre_emphasis)
         hipLaunchKernelGGL((featurize_kernel<true, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr);
     else
         hipLaunchKernelGGL((featurize_kernel<false, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr);
     COUGH_HIP_CHECK(hipGetLastError());
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)
         return launch_contrast(featurizer_stft_view(f), f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase,

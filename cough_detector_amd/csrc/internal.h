@@ -26,7 +26,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
                      size_t workspace_bytes = 0, int n_samples = 0);
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples = 0);
 int featurizer_num_features(const cough_featurizer* f);
-bool featurizer_stem_fusable(const cough_featurizer* f);   // shipped 90-row layout, no pre-emphasis, no PCEN
+bool featurizer_stem_fusable(const cough_featurizer* f, bool x3);   // 90-row layout on a one-launch kernel, no pre-emphasis / PCEN
 
 // Device tables of a featuriser that the stand-alone STFT (spectrogram.hip) shares.
 struct StftView {

@@ -1004,7 +1004,7 @@ int launch_conv(const cough_resnet* m, const ConvArgs<T>& a, hipStream_t st) {
 constexpr int RBX_G_TALL = 1;
 // block-input geometries resblock_x3_kernel is instantiated for (block index, rows, columns): every feature image the
 // reference's flags produce at 99..102 frames.  Image rows -> block-0 rows -> block-1 rows:
-//   64 (use_mfcc = False) 16 -> 8 | 65..68 (+ contrast rows) 17 -> 9 | 87..90 (shipped) 22 -> 11 | 91..94 (+ contrast rows) 23 -> 12 |
+//   63..66 (use_mfcc = False: 64) 16 -> 8 | 67..70 (+ contrast rows) 17 -> 9 | 87..90 (shipped) 22 -> 11 | 91..94 (+ contrast rows) 23 -> 12 |
 //   95..98 24 -> 12 | 103..106 (delta-delta on) 26 -> 13 | 107..110 (+ contrast rows: the constructor's defaults) 27 -> 14
 #define RBX_BLOCK0_ROWS(X) X(16) X(17) X(22) X(23) X(24) X(26) X(27)
 #define RBX_BLOCK1_ROWS(X) X(8) X(9) X(11) X(12) X(13) X(14)
@@ -1419,7 +1419,7 @@ extern "C" int cough_resnet_read_activation(const cough_resnet* m, const void* d
 namespace cough {
 namespace {
 bool can_fuse_stem(const cough_featurizer* f, const cough_resnet* m) {
-    return !m->gen && (m->dtype == COUGH_DTYPE_BF16 || m->dtype == COUGH_DTYPE_BF16X3) && featurizer_stem_fusable(f) &&
+    return !m->gen && (m->dtype == COUGH_DTYPE_BF16 || m->dtype == COUGH_DTYPE_BF16X3) && featurizer_stem_fusable(f, m->dtype == COUGH_DTYPE_BF16X3) &&
            cough_featurizer_num_frames(f) == 101;
 }
 }  // namespace

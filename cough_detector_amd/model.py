@@ -230,7 +230,7 @@ class CoughDetectorResidual(nn.Module):
         goes through ``cough_resnet_create_ex`` onto the exact-f32 MFMA kernels, and the split-bf16 residual blocks
         are compiled for the images the reference's own flags produce at 101 frames -- 90 rows (shipped; block inputs
         22x25 and 11x13), 103 rows (constructor defaults: delta-delta on; 26x25 / 13x13), 110 rows (+ contrast and
-        centroid rows; 27x25 / 14x13), 91..98 rows (contrast rows on the shipped set) and 61..68 rows (use_mfcc=False)
+        centroid rows; 27x25 / 14x13), 91..98 rows (contrast rows on the shipped set) and 63..70 rows (use_mfcc=False, 64 rows + contrast rows)
         -- another image size runs them in exact f32 as well.  Results are at least as
         accurate as asked for; throughput is the f32 path's."""
         if self.compute_dtype == "fp32":
@@ -239,7 +239,7 @@ class CoughDetectorResidual(nn.Module):
             return "fp32"
         if self.compute_dtype == "bf16x3":
             # the kernels are selected by the block-0 input (stem + pool output), csrc/resnet.hip rbx_compiled():
-            # 16x25 <- 61..64 rows, 17x25 <- 65..68, 22x25 <- 87..90, 23x25 <- 91..94, 24x25 <- 95..98, 26x25 <- 103..106,
+            # 16x25 <- 63..66 rows, 17x25 <- 67..70, 22x25 <- 87..90, 23x25 <- 91..94, 24x25 <- 95..98, 26x25 <- 103..106,
             # 27x25 <- 107..110, each x 99..102 frames: every image the reference's flags produce at 1 s
             p1 = (((height - 1) // 2 + 1) // 2, ((width - 1) // 2 + 1) // 2)
             if p1 not in self.X3_BLOCK_INPUTS:

@@ -140,6 +140,11 @@ class AudioPreprocessor:
                     self._handle = self._create_handle(self.segment_samples)
         return self._handle
 
+    def kernel_path(self) -> str:
+        """Which kernels featurise ``segment_samples`` windows: "tuned" (one launch, the shipped sparse filterbank),
+        "tuned_fullband" (one launch, any filterbank at the shipped STFT geometry) or "generic" (the kernel chain)."""
+        return ("generic", "tuned", "tuned_fullband")[_lib.load().cough_featurizer_path(self._native())]
+
     def _check_length(self, n_samples: int) -> None:
         if n_samples <= self.n_fft // 2:
             raise ValueError(f"a waveform of {n_samples} samples is shorter than the reflect padding of "

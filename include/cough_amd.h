@@ -92,6 +92,14 @@ int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg
 void cough_featurizer_destroy(cough_featurizer* f);
 int cough_featurizer_num_features(const cough_featurizer* f); /* get_num_features(), :536-550 */
 int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_time_frames(), :532-534 */
+/* Which kernels serve windows of segment_samples: COUGH_PATH_GENERIC (the kernel chain, needs a workspace), COUGH_PATH_TUNED
+ * (one launch; the shipped 64-mel / 13-MFCC layout with a filterbank of <= 8 taps per band below bin 128) or
+ * COUGH_PATH_TUNED_FULLBAND (one launch; any filterbank at the shipped STFT geometry -- 16 kHz, n_fft 512, hop 160, window 400,
+ * 1 s --: f_max up to the Nyquist bin, 2..128 mel bands (even), up to 20 MFCCs; PCEN with 64 bands). */
+#define COUGH_PATH_GENERIC 0
+#define COUGH_PATH_TUNED 1
+#define COUGH_PATH_TUNED_FULLBAND 2
+int cough_featurizer_path(const cough_featurizer* f);
 
 #define COUGH_FEAT_NORMALIZE 1 /* apply normalize() (peak, per clip) before extract_features */
 
@@ -188,9 +196,11 @@ typedef struct cough_resnet_weights {
 typedef struct cough_resnet cough_resnet;
 
 int cough_resnet_create(cough_resnet** out, const cough_resnet_weights* w, int dtype);
-/* The fused split-bf16 kernels of cough_resnet_create are compiled for the feature images the reference's own flags
- * produce at 101 frames: 90 rows (shipped), 103 rows (constructor defaults: delta-delta) and 110 rows (+ spectral
- * contrast / centroid); any other image size runs the exact-f32 kernels (same entry points, same results or better).
+/* The fused split-bf16 kernels of cough_resnet_create are compiled for every feature image the reference's own flags
+ * produce at 99..102 frames -- 13 instantiations, selected by the stem's output height ((rows - 1) / 2 + 1) / 2:
+ * 63..70 rows (use_mfcc = 0: 64 mel rows + contrast rows), 87..98 rows (shipped 90; + contrast rows) and 103..110 rows
+ * (delta-delta; + contrast rows: the constructor's defaults); any other image size runs the exact-f32 kernels (same entry
+ * points, same results or better).
  *
  * The same for any `channels` tuple of CoughDetectorResidual.__init__ (/root/reference/src/model.py:216-247):
  * channels[0 .. n_blocks] = (stem out, block 0 out, ..., block n_blocks-1 out); blocks[i] holds res_blocks.i;

@@ -21,7 +21,8 @@ NAN, INF = float("nan"), float("inf")
 BAD_SAMPLES = {"nan_first": (0, NAN), "nan_middle": (8000, NAN), "nan_last": (15999, NAN), "plus_inf": (777, INF),
                "minus_inf": (12345, -INF)}
 # tuned one-launch kernel (shipped geometry) and two geometries of the generic kernel chain
-GEOMETRIES = {"tuned": {}, "generic_hop200_40mel": dict(hop_length=200, n_mels=40), "generic_nfft400": dict(n_fft=400)}
+GEOMETRIES = {"tuned": {}, "tuned_fullband_fmax8k": dict(f_max=8000.0), "generic_hop200_40mel": dict(hop_length=200, n_mels=40),
+              "generic_nfft400": dict(n_fft=400)}
 
 
 def _oracle(w, normalize, geo, **flags):
@@ -46,6 +47,7 @@ def _same_with_nans(got, ref, tol=FEAT_TOL):
 @pytest.mark.parametrize("normalize", [False, True])
 def test_one_bad_sample_makes_the_whole_image_nan_and_leaves_the_neighbours_alone(geo, normalize):
     pre = cda.AudioPreprocessor(device="cuda", **SHIPPED, **GEOMETRIES[geo])
+    assert pre.kernel_path() == ("generic" if geo.startswith("generic") else geo[:14] if "fullband" in geo else "tuned")
     clean = synth_batch(300, len(BAD_SAMPLES) + 2, peak_normalize=False)
     w = clean.clone()
     for i, (pos, val) in enumerate(BAD_SAMPLES.values()):
@@ -60,7 +62,7 @@ def test_one_bad_sample_makes_the_whole_image_nan_and_leaves_the_neighbours_alon
     assert torch.equal(got[0], alone[0]) and torch.equal(got[-1], alone[-1])      # per-clip: the neighbours are bit-identical
 
 
-@pytest.mark.parametrize("geo", ["tuned", "generic_hop200_40mel"])
+@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_hop200_40mel"])
 @pytest.mark.parametrize("flags", [dict(use_delta_delta=True), dict(use_pcen=True, use_pre_emphasis=True),
                                    dict(use_mfcc=False), dict(use_spectral_contrast=True, n_contrast_bands=4),
                                    dict(use_pre_emphasis=True, use_delta_delta=True)],

@@ -301,6 +301,10 @@ def test_effective_dtype_reports_the_kernels_that_run():
     assert m.effective_dtype(103, 101) == "bf16x3" and m.effective_dtype(110, 101) == "bf16x3"     # the reference's own flags
     assert m.effective_dtype(100, 101) == "fp32" and m.effective_dtype(103, 201) == "fp32"
     assert all(m.effective_dtype(h, 101) == "bf16x3" for h in (64, 66, 67, 68, 92, 93, 94, 95))   # use_mfcc=False / 1..4 contrast bands
+    # the edges of the compiled ranges (stem output rows ((h - 1) // 2 + 1) // 2 in 16, 17 | 22..24 | 26, 27): 63..70, 87..98, 103..110
+    edges = {62: "fp32", 63: "bf16x3", 66: "bf16x3", 67: "bf16x3", 70: "bf16x3", 71: "fp32", 86: "fp32", 87: "bf16x3", 98: "bf16x3",
+             99: "fp32", 102: "fp32", 103: "bf16x3", 110: "bf16x3", 111: "fp32"}
+    assert {h: m.effective_dtype(h, 101) for h in edges} == edges
     assert all(m.effective_dtype(h, 101) == "bf16x3" for h in (105, 106, 107, 108, 109))   # + 1..5 contrast bands
     wide = cda.CoughDetectorResidual(channels=(16, 24, 40), compute_dtype="bf16x3")
     assert wide.effective_dtype() == "fp32" and wide.compute_dtype == "bf16x3"
