@@ -72,7 +72,8 @@ constexpr int IMG_PIECES = (IMG + 3 + 3) / 4;                           // 16-by
 constexpr size_t LDS3_IMG = size_t(IMG_PIECES) * 16;                    // 103 840
 constexpr size_t LDS3_XCH = size_t(W3) * X3WAVE * 4;                    // 54 080
 constexpr size_t LDS3_WIN = size_t(NFFT) * 4;                           // 2 048
-constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN;  // 162 144
+constexpr size_t LDS3_PK = 128;                                         // 2 x 13 wave maxima (per-clip peak, by clip parity)
+constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN + LDS3_PK;  // 162 272
 static_assert(LDS3_TOTAL <= 160 * 1024, "one workgroup owns the CU's LDS");
 static_assert(W3 * 2 == NGROUP, "13 waves x 2 rounds = 26 groups");
 static_assert(GSPAN <= X3WAVE && GSPAN % 4 == 0, "a group's samples land in the wave's transpose scratch");
@@ -106,16 +107,23 @@ __device__ __forceinline__ void lds_barrier() {   // LDS hand-off between waves;
 #define STFT3_STAMP(slot) do {} while (0)
 #endif
 
-template <bool FULLWIN, bool MAG>
+// CENT: centroid mode (the spectral-contrast path): no image, no flush -- every frame reduces sum(k 31.25 Hz |X[k]|) / sum |X[k]| /
+// 8000 over its 16 lanes and `out` is [n_clips][101] (torchaudio.functional.spectral_centroid / (sample_rate / 2),
+// /root/reference/src/preprocessing.py:295-298, with FULLWIN + MAG).  VMW: flush-store instructions every wave is guaranteed to
+// issue behind its DMA (the counted wait below); 7 for the whole image, less when only the first `rows_out` bins are flushed
+// (the contrast path needs the bins below its last band edge; VMW = 7 always flushes all 257).  PEAK: also write max |sample| per clip.
+template <bool FULLWIN, bool MAG, bool CENT = false, int VMW = 7, bool PEAK = false>
 __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict__ wav, long long wav_stride,
                                                          float* __restrict__ out, const float* __restrict__ win,
                                                          const float2* __restrict__ tw256,
-                                                         const float2* __restrict__ tw512, int n_clips) {
+                                                         const float2* __restrict__ tw512, int n_clips, int rows_out,
+                                                         float* __restrict__ peaks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* img0 = reinterpret_cast<float*>(smem);                                       // the clip's image (+ lead-in)
     float* xs = reinterpret_cast<float*>(smem + LDS3_IMG);                              // [W3][X3WAVE]
     float2* twl = reinterpret_cast<float2*>(smem + LDS3_IMG + LDS3_XCH);                // [16][XROW]
     float* winl = reinterpret_cast<float*>(smem + LDS3_IMG + LDS3_XCH + LDS_TW);        // [512]
+    float* pkred = reinterpret_cast<float*>(smem + LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN);   // [2][W3] wave maxima of |sample|
     constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,12 +180,13 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
 #endif
 
     bool first = true;
+    [[maybe_unused]] int parity = 0;
     while (true) {
         STFT3_STAMP(0);
         const long long clip_n = clip + gridDim.x;
         // the image sits `lead` floats into its region so that LDS and global addresses agree modulo 16 bytes
-        float* oc = out + clip * (long long)IMG;
-        const int lead = int((reinterpret_cast<size_t>(oc) >> 2) & 3);
+        float* oc = out + clip * (long long)(CENT ? NFRAMES : IMG);
+        const int lead = CENT ? 0 : int((reinterpret_cast<size_t>(oc) >> 2) & 3);
         float* img = img0 + lead;
 #pragma unroll 1
         for (int rd = 0; rd < 2; ++rd) {
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             // (IMG_PIECES - 2) / THREADS3 of them.  A build without the stores has nothing behind the DMA: vmcnt(0).
             static_assert((IMG_PIECES - 2) / THREADS3 >= 7, "round 0 waits with vmcnt(7): every wave must issue >= 7 flush stores after its DMA");
 #ifndef COUGH_STFT_NO_STORE
-            if (rd == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            if (rd == 0 && !CENT && VMW > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,11 +211,21 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             }
             const float* sp = myw + HOP * fsub + 2 * j;
             const float* wp = winl + 2 * j;
+            [[maybe_unused]] float gp = 0.f;   // PEAK: max |sample| under this group's live window taps
 #pragma unroll
             for (int n1 = N0; n1 < N1; ++n1) {
                 const float2 r = *reinterpret_cast<const float2*>(sp + 32 * n1);
                 const float2 w = *reinterpret_cast<const float2*>(wp + 32 * n1);
                 a[n1] = make_float2(r.x * w.x, r.y * w.y);
+                if constexpr (PEAK) gp = fmaxf(gp, fmaxf(fabsf(r.x), fabsf(r.y)));
+            }
+            if constexpr (PEAK) {
+                // the wave's running maximum lives in LDS (a register held across the clip spilled: the kernel sits at 128 VGPRs);
+                // two slots by clip parity -- a wave runs at most one clip ahead of the thread that combines them
+                if (FPW * g + fsub >= NFRAMES) gp = 0.f;   // idle sub-frames of the last group hold stale samples
+                gp = wave_max(gp);
+                float* slot = pkred + W3 * (parity & 1) + wave;
+                if (lane == 0) *slot = rd == 0 ? gp : fmaxf(*slot, gp);
             }
             wave_lds_fence();
             dft16(a);
@@ -241,7 +260,38 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             };
             // the previous clip's flush has read the image: that barrier sits HERE, not behind the flush, so a wave
             // that finished flushing early is already through the window / first radix-16 / transposes of this clip
-            if (rd == 0 && !first) lds_barrier();
+            if (!CENT && rd == 0 && !first) lds_barrier();
+            if constexpr (CENT) {
+                // centroid of this frame: lane j holds bins j + 16 k2, 256 - (j + 16 k2) (and lane 0 bin 128); freqs =
+                // torch.linspace(0, 8000, 257) = 31.25 k exactly
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 zk = z[k2];
+                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];
+                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+                    const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+                    const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+                    const int k = j + 16 * k2;
+                    const float ma = 0.5f * sqrtf(ar * ar + ai * ai), mb = 0.5f * sqrtf(br * br + bi * bi);
+                    num += (31.25f * float(k)) * ma + (31.25f * float(NFFT / 2 - k)) * mb;
+                    den += ma + mb;
+                }
+                if (j == 0) {
+                    const float m128 = sqrtf(z[8].x * z[8].x + z[8].y * z[8].y);   // |X[128]| = |Z[128]|
+                    num += 4000.0f * m128;
+                    den += m128;
+                }
+                // totals of the frame's 16 lanes (a DPP row)
+                num += dpp_mov<0xB1>(num); den += dpp_mov<0xB1>(den);
+                num += dpp_mov<0x4E>(num); den += dpp_mov<0x4E>(den);
+                num += dpp_mov<0x141>(num); den += dpp_mov<0x141>(den);
+                num += dpp_mov<0x140>(num); den += dpp_mov<0x140>(den);
+                if (j == 0 && FPW * g + fsub < NFRAMES) oc[FPW * g + fsub] = (num / den) / 8000.0f;   // / (sample_rate / 2), :297
+            } else
             if (FPW * g + fsub < NFRAMES) {   // idle sub-frames of the last group store nothing
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
@@ -263,16 +313,28 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             if (rd == 0) STFT3_STAMP(4);
         }
         STFT3_STAMP(5);
-        lds_barrier();
+        if constexpr (!CENT) lds_barrier();
+        if constexpr (PEAK) {   // per-clip peak of normalize() (:199-212): the waves' maxima, combined behind the barrier
+            if (tid == 0) {
+                const float* slot = pkred + W3 * (parity & 1);
+                float m = slot[0];
+#pragma unroll
+                for (int w = 1; w < W3; ++w) m = fmaxf(m, slot[w]);
+                peaks[clip] = m;
+            }
+            ++parity;
+        }
         STFT3_STAMP(6);
 #ifndef COUGH_STFT_NO_STORE
-        {
+        if constexpr (!CENT) {
             // flush: the image is the clip's output range verbatim; piece p = LDS floats [4p, 4p + 4) = image elements
             // [4p - lead, 4p - lead + 4) -> one 16-byte store at a 16-byte-aligned address.  The first and last piece
             // may hold elements of the neighbouring clips' ranges: those two go out float by float.
+            // rows_out < 257: only bins [0, rows_out) leave the CU (the contrast path reads the bins below its last band edge)
+            const int n_out = (VMW == 7 ? NFREQ : rows_out) * NFRAMES;
             const f32x4* src = reinterpret_cast<const f32x4*>(img0);
             f32x4* dst = reinterpret_cast<f32x4*>(oc - lead);
-            const int last = (IMG + lead + 3) / 4 - 1;
+            const int last = (n_out + lead + 3) / 4 - 1;
 #pragma unroll
             for (int it = 0; it < (IMG_PIECES + THREADS3 - 1) / THREADS3; ++it) {
                 const int p = tid + THREADS3 * it;
@@ -280,7 +342,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             }
             if (tid < 8) {   // element e of the first (tid < 4) or last piece
                 const int e = (tid < 4 ? 0 : 4 * last) + (tid & 3) - lead;
-                if (e >= 0 && e < IMG) oc[e] = img[e];
+                if (e >= 0 && e < n_out) oc[e] = img[e];
             }
         }
 #endif
@@ -311,82 +373,99 @@ __device__ __forceinline__ float ct_block_sum(float v, float* red, int tid) {
     __syncthreads();
     return red[0] + red[1];
 }
-__device__ __forceinline__ float ct_block_max(float v, float* red, int tid) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    return fmaxf(red[0], red[1]);
+
+// Sums of the CAP-limited largest / smallest values of one frame's band, i.e. of the reference's sorted slices
+// `sorted_band[top_idx:]` / `sorted_band[:bot_idx]` (:279-290) without sorting: the band streams past once while the frame keeps
+// its k largest and k smallest values so far in registers (an insertion network of max / min pairs, 4 CAP operations per value;
+// the rank count it replaces -- contrast_rank.h, still used by the generic chain -- costs 2 nb per value).  Equal values give the
+// same sums whatever their order, so torch.sort's tie rule is immaterial; max / min drop a NaN, so non-finite powers are
+// tracked in `chk` (v * 0) and poison the result as the reference's NaN-last sort + mean would.
+template <int CAP>
+__device__ __forceinline__ void select_sums(const float* __restrict__ col, int nb, int ktop, int kbot, float scale, float& top,
+                                            float& bot, float& chk) {
+    float hi[CAP], lo[CAP];
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) {
+        hi[i] = -INFINITY;
+        lo[i] = INFINITY;
+    }
+#pragma unroll 4
+    for (int k = 0; k < nb; ++k) {
+        const float v = col[k * NFRAMES] * scale;
+        chk = fmaf(v, 0.f, chk);
+        float x = v, y = v;
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {   // hi: descending
+            const float m = fmaxf(hi[i], x);
+            x = fminf(hi[i], x);
+            hi[i] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {   // lo: ascending
+            const float m = fminf(lo[i], y);
+            y = fmaxf(lo[i], y);
+            lo[i] = m;
+        }
+    }
+    top = 0.f;
+    bot = 0.f;
+#pragma unroll
+    for (int i = CAP - 1; i >= 0; --i)   // ascending, as the sorted slice is summed
+        if (i < ktop) top += hi[i];
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+        if (i < kbot) bot += lo[i];
 }
 
-__global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __restrict__ power,
-                                                             const float* __restrict__ magn,
-                                                             const float* __restrict__ wav, long long wav_stride,
-                                                             float* __restrict__ feat, int nfeat, int row0,
-                                                             ContrastCfg cfg, int normalize) {
-    extern __shared__ __attribute__((aligned(16))) float4 band4[];   // [quads of the widest band][NFRAMES], contrast_rank.h
+// One 128-thread workgroup per clip, thread = frame: band contrasts out of the power rows the STFT kernel left in the workspace
+// (read once, straight from L2: consecutive frames are consecutive addresses), the centroid row from the centroid-mode STFT
+// pass, the joint z-score (:300), rows stored behind the MFCC block.
+__global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __restrict__ power, const float* __restrict__ centroid,
+                                                             const float* __restrict__ peaks, float* __restrict__ feat,
+                                                             int nfeat, int row0, ContrastCfg cfg, int normalize) {
     __shared__ float cr[(COUGH_MAX_CONTRAST_BANDS + 1) * NFRAMES];
     __shared__ float red[2];
     const int tid = threadIdx.x;
     const long long clip = blockIdx.x;
     const float* P = power + clip * (long long)NFREQ * NFRAMES;
-    const float* M = magn + clip * (long long)NFREQ * NFRAMES;
     const int nb_rows = cfg.n_bands + 1;
-
-    // normalize() (preprocessing.py:199-212) scales the waveform by 1/peak, i.e. the power by 1/peak^2; the
-    // centroid is a ratio and does not change
+    // normalize() (preprocessing.py:199-212) scales the waveform by 1/peak, i.e. the power by 1/peak^2; the centroid is a ratio
+    // and does not change.  A NaN peak cannot occur (v_max drops it): such a clip is NaN through its powers.
     float scale = 1.0f;
     if (normalize) {
-        const float* x = wav + clip * wav_stride;
-        float m = 0.f;
-        for (int i = tid; i < NS / 4; i += CT_THREADS) {
-            const float4 v = reinterpret_cast<const float4*>(x)[i];
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        }
-        m = ct_block_max(m, red, tid);
+        const float m = peaks[clip];
         if (m > 0.f) {
             const float inv = 1.0f / m;
             scale = inv * inv;
         }
     }
-    for (int i = 0; i < cfg.n_bands; ++i) {
+    for (int i = 0; i < cfg.n_bands; ++i) {   // workgroup-uniform control flow
         int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
         if (high <= low) high = low + 1;
         if (high > NFREQ) high = NFREQ;
-        const int nb = high - low, nq = (nb + 3) >> 2;
-        __syncthreads();
-        if (tid < NFRAMES)
-            for (int q = 0; q < nq; ++q) {
-                const float* src = P + (low + 4 * q) * NFRAMES + tid;
-                float4 u;
-                u.x = src[0] * scale;
-                u.y = 4 * q + 1 < nb ? src[NFRAMES] * scale : __builtin_nanf("");
-                u.z = 4 * q + 2 < nb ? src[2 * NFRAMES] * scale : __builtin_nanf("");
-                u.w = 4 * q + 3 < nb ? src[3 * NFRAMES] * scale : __builtin_nanf("");
-                band4[q * NFRAMES + tid] = u;
-            }
-        __syncthreads();
+        const int nb = high - low;
+        int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
+        if (top_idx < 1) top_idx = 1;
+        if (bot_idx < 1) bot_idx = 1;
+        const int ktop = nb - top_idx, kbot = bot_idx < nb ? bot_idx : nb, cap = ktop > kbot ? ktop : kbot;
         if (tid < NFRAMES) {
-            int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
-            if (top_idx < 1) top_idx = 1;
-            if (bot_idx < 1) bot_idx = 1;
-            float top, bot;
-            contrast_band_sums(band4, NFRAMES, tid, nb, top_idx, bot_idx, top, bot);
-            const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
-            const float valleys = bot / float(bot_idx);
-            cr[i * NFRAMES + tid] = log1pf(peaks) - log1pf(valleys);
+            const float* col = P + low * NFRAMES + tid;
+            float top, bot, chk = 0.f;
+            if (cap <= 1) select_sums<1>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 2) select_sums<2>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 3) select_sums<3>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 4) select_sums<4>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 6) select_sums<6>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 8) select_sums<8>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 13) select_sums<13>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else if (cap <= 18) select_sums<18>(col, nb, ktop, kbot, scale, top, bot, chk);
+            else select_sums<26>(col, nb, ktop, kbot, scale, top, bot, chk);   // nb <= 128: at most 26 values per slice
+            const float pk = top / float(ktop);   // 0 / 0 = NaN when the top slice is empty (one-bin band), as mean() of an empty tensor
+            const float valleys = bot / float(kbot);
+            cr[i * NFRAMES + tid] = (log1pf(pk) - log1pf(valleys)) + chk;
         }
     }
-    if (tid < NFRAMES) {
-        // torchaudio.functional.spectral_centroid: freqs = linspace(0, sr // 2, 257) = k * 31.25 exactly
-        float num = 0.f, den = 0.f;
-        for (int k = 0; k < NFREQ; ++k) {
-            const float m = M[k * NFRAMES + tid];
-            num += (31.25f * float(k)) * m;
-            den += m;
-        }
-        cr[cfg.n_bands * NFRAMES + tid] = (num / den) / 8000.0f;   // / (sample_rate / 2), :297
-    }
+    if (tid < NFRAMES) cr[cfg.n_bands * NFRAMES + tid] = centroid[clip * NFRAMES + tid];
     __syncthreads();
     // (contrast - mean) / (std + 1e-8) over all rows, std unbiased (:300)
     const int total = nb_rows * NFRAMES;
@@ -404,37 +483,63 @@ __global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __res
     for (int i = tid; i < total; i += CT_THREADS) o[i] = (cr[i] - mean) * rden;
 }
 
-constexpr int CT_SUB_BATCH = 1024;   // clips per workspace fill: 2 x 1024 x 103 828 B = 213 MB
+constexpr int CT_SUB_BATCH = 2048;   // clips per workspace fill: 2048 x 103 828 B = 213 MB of power rows (Infinity-Cache sized)
+
+struct CtCarve {
+    size_t sub, o_cent, o_peak, total;
+};
+CtCarve ct_carve(int n_clips) {
+    CtCarve c;
+    c.sub = size_t(n_clips < CT_SUB_BATCH ? n_clips : CT_SUB_BATCH);
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    c.o_cent = al(c.sub * NFREQ * NFRAMES * sizeof(float));
+    c.o_peak = c.o_cent + al(c.sub * NFRAMES * sizeof(float));
+    c.total = c.o_peak + al(c.sub * sizeof(float));
+    return c;
+}
 
 }  // namespace
 
-size_t contrast_workspace_bytes(int n_clips) {
-    const size_t sub = n_clips < CT_SUB_BATCH ? n_clips : CT_SUB_BATCH;
-    return 2 * ((sub * NFREQ * NFRAMES * sizeof(float) + 255) & ~size_t(255));
-}
+size_t contrast_workspace_bytes(int n_clips) { return ct_carve(n_clips).total; }
 
 int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
                     int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
                     hipStream_t stream) {
-    COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
+    const CtCarve c = ct_carve(n_clips);
+    COUGH_REQUIRE(d_workspace && workspace_bytes >= c.total, COUGH_EWORKSPACE,
                   "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
     COUGH_REQUIRE((reinterpret_cast<size_t>(d_workspace) & 255) == 0, COUGH_EINVAL, "workspace must be 256-byte aligned");
-    const size_t half = contrast_workspace_bytes(n_clips) / 2;
     float* pw = static_cast<float*>(d_workspace);
-    float* mg = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + half);
-    int widest = 1;
+    float* cent = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + c.o_cent);
+    float* peaks = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + c.o_peak);
+    int widest = 1, rows_out = 1;   // rows_out: bins below the last band's upper edge -- the only power rows anybody reads
     for (int i = 0; i < cfg.n_bands; ++i) {
-        const int lo = cfg.edges[i], hi = cfg.edges[i + 1] > NFREQ ? NFREQ : cfg.edges[i + 1];
+        int lo = cfg.edges[i], hi = cfg.edges[i + 1];
+        if (hi <= lo) hi = lo + 1;
+        if (hi > NFREQ) hi = NFREQ;
         if (hi - lo > widest) widest = hi - lo;
+        if (hi > rows_out) rows_out = hi;
     }
     COUGH_REQUIRE(widest <= CT_MAX_BINS, COUGH_EUNSUPPORTED, "spectral-contrast band of %d bins (<= %d)", widest, CT_MAX_BINS);
-    const size_t ct_lds = size_t((widest + 3) / 4) * NFRAMES * sizeof(float4);   // <= 51 712 B
-    for (int c0 = 0; c0 < n_clips; c0 += CT_SUB_BATCH) {
-        const int nc = n_clips - c0 < CT_SUB_BATCH ? n_clips - c0 : CT_SUB_BATCH;
+    // flush-store instructions per wave the power pass is sure to issue (its counted wait, stft3_kernel VMW)
+    const int pieces = (rows_out * NFRAMES + 3 + 3) / 4, sure = (pieces - 2) / THREADS3;
+    for (int c0 = 0; c0 < n_clips; c0 += int(c.sub)) {
+        const int nc = n_clips - c0 < int(c.sub) ? n_clips - c0 : int(c.sub);
         const float* w = d_wav + (long long)c0 * wav_stride;
-        if (int e = launch_stft(v, w, wav_stride, pw, nc, 0, stream)) return e;
-        if (int e = launch_stft(v, w, wav_stride, mg, nc, COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW, stream)) return e;
-        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), ct_lds, stream, pw, mg, w, wav_stride,
+        const dim3 grid3(nc < v.n_cus ? nc : v.n_cus), block3(THREADS3);
+        float* pk = normalize ? peaks : nullptr;
+        (void)pk;
+#define COUGH_STFT_POWER(V) hipLaunchKernelGGL((stft3_kernel<false, false, false, V, true>), grid3, block3, LDS3_TOTAL, stream, w, \
+                                               wav_stride, pw, v.win, v.tw256, v.tw512, nc, rows_out, peaks)
+        if (sure >= 7) COUGH_STFT_POWER(7);
+        else if (sure >= 3) COUGH_STFT_POWER(3);
+        else if (sure >= 2) COUGH_STFT_POWER(2);
+        else if (sure >= 1) COUGH_STFT_POWER(1);
+        else COUGH_STFT_POWER(0);
+#undef COUGH_STFT_POWER
+        hipLaunchKernelGGL((stft3_kernel<true, true, true>), grid3, block3, LDS3_TOTAL, stream, w, wav_stride, cent, v.win_full,
+                           v.tw256, v.tw512, nc, 0, static_cast<float*>(nullptr));
+        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), 0, stream, pw, cent, peaks,
                            d_feat + (long long)c0 * nfeat * NFRAMES, nfeat, row0, cfg, normalize);
         COUGH_HIP_CHECK(hipGetLastError());
     }
@@ -449,10 +554,10 @@ int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, flo
     // the > 64 KB dynamic-LDS attribute of the four instantiations is set per device by stft_prepare_device (called from
     // cough_featurizer_create on the featuriser's device), not lazily here: the attribute is per device and a launch
     // path must not carry process-wide mutable state
-    if (full && mag) hipLaunchKernelGGL((stft3_kernel<true, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
-    else if (full) hipLaunchKernelGGL((stft3_kernel<true, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
-    else if (mag) hipLaunchKernelGGL((stft3_kernel<false, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
-    else hipLaunchKernelGGL((stft3_kernel<false, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips);
+    if (full && mag) hipLaunchKernelGGL((stft3_kernel<true, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
+    else if (full) hipLaunchKernelGGL((stft3_kernel<true, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
+    else if (mag) hipLaunchKernelGGL((stft3_kernel<false, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
+    else hipLaunchKernelGGL((stft3_kernel<false, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
@@ -462,8 +567,14 @@ int stft_prepare_device(int* n_cus) {
     COUGH_HIP_CHECK(hipGetDevice(&dev));
     COUGH_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     *n_cus = cus > 0 ? cus : 256;
-    const void* fns[4] = {reinterpret_cast<const void*>(stft3_kernel<false, false>), reinterpret_cast<const void*>(stft3_kernel<false, true>),
-                          reinterpret_cast<const void*>(stft3_kernel<true, false>), reinterpret_cast<const void*>(stft3_kernel<true, true>)};
+    const void* fns[] = {reinterpret_cast<const void*>(stft3_kernel<false, false>), reinterpret_cast<const void*>(stft3_kernel<false, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<true, false>), reinterpret_cast<const void*>(stft3_kernel<true, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<false, false, false, 7, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<false, false, false, 3, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<false, false, false, 2, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<false, false, false, 1, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<false, false, false, 0, true>),
+                         reinterpret_cast<const void*>(stft3_kernel<true, true, true>)};
     for (const void* fn : fns)
         COUGH_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS3_TOTAL));
     return COUGH_OK;

@@ -369,3 +369,26 @@ def test_helper_methods_called_on_their_own():
         assert err < 1e-5
     with pytest.raises(ValueError, match="apply_pcen"):
         off.apply_pcen(mel[0])
+
+
+@pytest.mark.parametrize("edges", [[3, 30, 130, 257], [10, 95, 257], [1, 2, 4, 10, 257], [0, 128, 257]],
+                         ids=["27_and_100_bins", "85_bins", "narrow", "128_bins_from_dc"])
+def test_contrast_selection_networks_of_every_size(monkeypatch, edges):
+    """The sorted-slice sums of the contrast rows are register-resident selection networks instantiated for 1 .. 26 values per
+    slice (spectrogram.hip: select_sums<CAP>); the reference's own logspace edges only reach a few of the sizes.  Same
+    arithmetic with custom band edges (``contrast_edges`` is a field of the C-ABI's config), on both sides."""
+    from cough_detector_amd import _tables
+    n_bands = len(edges) - 2
+    monkeypatch.setattr(_tables, "contrast_band_edges", lambda nb, nf: list(edges))
+    monkeypatch.setattr(ofeat, "contrast_band_edges", lambda nb=6, nf=257: list(edges))
+    flags = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=True,
+                 n_contrast_bands=n_bands)
+    p = cda.AudioPreprocessor(device="cuda", **flags)
+    w = synth_batch(700, 12, peak_normalize=False)
+    for normalize in (False, True):
+        got = p.featurize_batch(w.cuda(), normalize=normalize).cpu()[:, 90:]
+        ref = ofeat.extract_features_batch(w, normalize_first=normalize, **flags)[:, 90:]
+        assert got.shape == ref.shape == (12, n_bands + 1, 101) and torch.isfinite(ref).all()
+        err = (got - ref).abs().max().item()
+        print(f"edges {edges} normalize={normalize}: abs err {err:.2e}")
+        assert err < 2e-5
