@@ -166,7 +166,11 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps) {
 // butterfly, as the stand-alone STFT does), the filterbank is a CSR table in LDS (lane = band, a band's taps in ascending bin
 // order), n_mels / n_mfcc are run-time sizes and the dB buffer is sized by them.  The shipped instantiations (FULL = false) keep
 // their <= 8 register taps per band below bin 128 and compile-time sizes.
-template <bool PRE_EMPH, int STEM, bool FULL = false>
+// TALL: the fused split-bf16 stem for the 103-row image of the reference's delta-delta flag (64 mel + 13 MFCC + 13 delta + 13
+// delta-delta; src/preprocessing.py:43-49, :471-474).  Its hi + lo images (2 x 23 KB) do not fit beside the MFCC / delta
+// buffers in a workgroup's 45.5 KB, so the stem runs in two halves of 13 pooled rows out of a 58-row image each -- three
+// workgroups per CU as for the shipped layout.
+template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
@@ -656,6 +660,157 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         img[idx] = hi;
         if constexpr (STEM == 2) img_lo[idx] = f2bf(v - __uint_as_float(uint32_t(hi) << 16));
     };
+    if constexpr (TALL) {
+        static_assert(!TALL || (STEM == 2 && !FULL), "the 103-row stem: split-bf16 operands, shipped filterbank");
+        // ---- 103-row image (delta-delta on), stem in two halves.  Half h covers pooled rows [13 h, 13 h + 13) = conv rows
+        // [26 h, 26 h + 26) = image rows (feature row + 3) [52 h, 52 h + 57): half 0 is mel rows 0..53 under the top border, half 1
+        // mel rows 49..63, the MFCC / delta / delta-delta rows and the bottom border.  LDS: MFCC + delta buffers (10.5 KB) | hi + lo
+        // partial images (2 x 12 296 B) | the 15 mel rows half 1 needs again (6 KB), all inside the workgroup's 45.5 KB.
+        constexpr int TL_P1H = 26, TL_HALF = 13, TL_PER = TL_HALF * ST_P1W, TL_ROWS = 58, TL_PLANE = TL_ROWS * ST_PITCH;
+        constexpr size_t TL_IMG_OFF = (size_t(2) * NMF * 4 + 15) & ~size_t(15), TL_STASH_OFF = TL_IMG_OFF + size_t(2) * TL_PLANE * 2;
+        constexpr int TL_KEEP0 = 2 * 2 * TL_HALF - 3;   // 49: first feature row of half 1
+        static_assert(TL_STASH_OFF % 16 == 0 && TL_STASH_OFF + size_t(NMEL - TL_KEEP0) * NFRAMES * 4 <= LDS_TOTAL, "103-row stem LDS");
+        static_assert(2 * (2 * (TL_HALF - 1) + 1) + 1 + 6 < TL_ROWS && TL_P1H == 2 * TL_HALF, "partial image rows");
+        constexpr int NDV = (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS;
+        float2 dv[NDV];   // the floored dB values move to registers: the dB buffer becomes image / stash space
+#pragma unroll
+        for (int it = 0; it < NDV; ++it) {
+            const int i2 = tid + it * THREADS;
+            dv[it] = i2 < NMEL * NFRAMES / 2 ? reinterpret_cast<const float2*>(melbuf)[i2] : make_float2(0.f, 0.f);
+        }
+        float* o_mfcc = o + NMEL * NFRAMES;
+        float* o_delta = o_mfcc + NMF;
+        for (int item = tid; item < NMF; item += THREADS) {
+            const int c = item / NFRAMES, t = item - c * NFRAMES;
+            const float* row = mf + c * NFRAMES;
+            const float d = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;   // :353-355
+            if (wr) {
+                o_mfcc[item] = row[t];
+                o_delta[item] = d;
+            }
+            dl[item] = d;
+        }
+        __syncthreads();
+        auto ddelta = [&](int c, int t) {
+            const float* row = dl + c * NFRAMES;
+            return (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
+        };
+        if (wr) {
+            float* o_dd = o_delta + NMF;
+            for (int item = tid; item < NMF; item += THREADS) o_dd[item] = ddelta(item / NFRAMES, item % NFRAMES);
+        }
+        uint16_t* timg = reinterpret_cast<uint16_t*>(smem + TL_IMG_OFF);
+        float* stash = reinterpret_cast<float*>(smem + TL_STASH_OFF);
+        auto tput = [&](int idx, float v) {
+            const uint16_t hi = f2bf(v);
+            timg[idx] = hi;
+            timg[TL_PLANE + idx] = f2bf(v - __uint_as_float(uint32_t(hi) << 16));
+        };
+        auto zero_image = [&]() {
+            for (int i = tid; i < 2 * TL_PLANE / 8; i += THREADS) reinterpret_cast<uint4*>(timg)[i] = make_uint4(0, 0, 0, 0);
+            for (int i = (2 * TL_PLANE / 8) * 8 + tid; i < 2 * TL_PLANE; i += THREADS) timg[i] = 0;
+            __syncthreads();
+        };
+        zero_image();
+        {
+            {
+#pragma unroll
+                for (int it = 0; it < NDV; ++it) {
+                    const int e = 2 * (tid + it * THREADS);
+                    if (e < NMEL * NFRAMES) {
+                        const int m0 = e / NFRAMES, t0 = e - m0 * NFRAMES;
+                        const int m1 = t0 + 1 < NFRAMES ? m0 : m0 + 1, t1 = t0 + 1 < NFRAMES ? t0 + 1 : 0;
+                        const float v0 = fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f);
+                        const float v1 = fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f);
+                        if (m0 + 3 < TL_ROWS - 1) tput((m0 + 3) * ST_PITCH + t0 + 3, v0);
+                        if (m1 + 3 < TL_ROWS - 1) tput((m1 + 3) * ST_PITCH + t1 + 3, v1);
+                        if (m0 >= TL_KEEP0) stash[(m0 - TL_KEEP0) * NFRAMES + t0] = v0;
+                        if (m1 >= TL_KEEP0) stash[(m1 - TL_KEEP0) * NFRAMES + t1] = v1;
+                    }
+                }
+            }
+        }
+        // the stem's weight fragments arrive only now: the 26 registers of floored dB values are dead
+        const int sr = lane & 31, sh = lane >> 5;
+        bf16x8 bw[2][4];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                bw[pl][st] = *reinterpret_cast<const bf16x8*>(stem.wfrag + pl * 2048 + ((st * 2 + sh) * 32 + sr) * 8);
+        const float bn = stem.bias[sr];
+        const int q = sr >> 2, dy = (sr >> 1) & 1, dx = sr & 1;
+        float* oa = reinterpret_cast<float*>(stem.a1) + clip * (long long)(TL_P1H * ST_P1W) * 32;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1) {
+                zero_image();
+                // image row = feature row + 3 - 52: mel 49..63 -> 0..14, MFCC -> 15.., delta -> 28.., delta-delta -> 41..53
+                for (int i = tid; i < (NMEL - TL_KEEP0) * NFRAMES; i += THREADS) {
+                    const int m = i / NFRAMES, t = i - m * NFRAMES;
+                    tput(m * ST_PITCH + t + 3, stash[i]);
+                }
+                for (int item = tid; item < NMF; item += THREADS) {
+                    const int c = item / NFRAMES, t = item - c * NFRAMES;
+                    tput((NMEL - TL_KEEP0 + c) * ST_PITCH + t + 3, mf[item]);
+                    tput((NMEL - TL_KEEP0 + NMFCC + c) * ST_PITCH + t + 3, dl[item]);
+                    tput((NMEL - TL_KEEP0 + 2 * NMFCC + c) * ST_PITCH + t + 3, ddelta(c, t));
+                }
+            }
+            __syncthreads();
+            // stem tiles of this half: 325 pooled positions = 41 tiles of 8; a wave takes two tiles at a time so that one tile's LDS
+            // latency and epilogue overlap the other's MFMAs (see the 90-row stem below for the fragment layout)
+            auto tl_base = [&](int tile) -> const uint32_t* {
+                int P = tile * 8 + q;
+                if (P >= TL_PER) P = TL_PER - 1;
+                const int ph = P / ST_P1W, pw = P - ph * ST_P1W;
+                return reinterpret_cast<const uint32_t*>(timg + (2 * (2 * ph + dy) + sh) * ST_PITCH + 2 * (2 * pw + dx));
+            };
+            auto tl_load = [&](const uint32_t* base, bf16x8 (&fa)[2][4]) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const uint32_t* pp = base + pl * (TL_PLANE / 2) + st * ST_PITCH;
+                        union { uint32_t u[4]; bf16x8 v; } tv;
+                        tv.u[0] = pp[0]; tv.u[1] = pp[1]; tv.u[2] = pp[2]; tv.u[3] = pp[3];
+                        fa[pl][st] = tv.v;
+                    }
+            };
+            auto tl_mma = [&](const bf16x8 (&fa)[2][4], f32x16& c) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][st], bw[0][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][st], bw[0][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][st], bw[1][st], c, 0, 0, 0);
+                }
+            };
+            auto tl_store = [&](int tile, const f32x16& acc2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int Po = tile * 8 + 2 * g + sh;
+                    float v = fmaxf(fmaxf(acc2[4 * g], acc2[4 * g + 1]), fmaxf(acc2[4 * g + 2], acc2[4 * g + 3])) + bn;
+                    v = fmaxf(v, 0.f);
+                    if (Po < TL_PER) oa[(half * TL_PER + Po) * 32 + sr] = v;
+                }
+            };
+            constexpr int TL_TILES = (TL_PER + 7) / 8;
+            for (int ta = wave; ta < TL_TILES; ta += 2 * WAVES) {
+                const int tb = ta + WAVES;
+                const bool two = tb < TL_TILES;   // wave-uniform
+                bf16x8 fa[2][4], fb[2][4];
+                tl_load(tl_base(ta), fa);
+                tl_load(tl_base(two ? tb : ta), fb);
+                f32x16 ca = {0}, cb = {0};
+                tl_mma(fa, ca);
+                tl_mma(fb, cb);
+                tl_store(ta, ca);
+                if (two) tl_store(tb, cb);
+            }
+            __syncthreads();   // the next half re-uses the image
+        }
+        return;
+    }
     if constexpr (STEM != 0) {
         // the floored dB values move to registers, then the dB buffer becomes the zero-bordered bf16 image
         float2 dv[(NMEL * NFRAMES / 2 + THREADS - 1) / THREADS];
@@ -697,7 +852,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         }
     }
     K1_STAMP(6);
-    if (delta_delta == 1) {
+    if (delta_delta == 1 && wr) {
         __syncthreads();
         float* o_dd = o_delta + nmf;
         for (int item = tid; item < nmf; item += THREADS) {
@@ -1017,9 +1172,13 @@ int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
 bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->kind != 0 && (n_samples <= 0 || n_samples == NS); }
 bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
+    if (f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->cfg.use_pre_emphasis || f->cfg.use_pcen ||
+        f->nfeat != f->nbase)
+        return false;
     // the 90-row layout (64 mel + 13 MFCC + 13 delta); the full-band kernel is instantiated for the split-bf16 stem only
-    return (f->kind == 1 || (f->kind == 2 && x3)) && f->cfg.n_mels == NMEL && f->cfg.n_mfcc == NMFCC && f->nfeat == ST_H &&
-           f->nbase == ST_H && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
+    if (f->nfeat == ST_H) return f->kind == 1 || (f->kind == 2 && x3);
+    // the 103-row layout of the delta-delta flag: split-bf16 stem in two halves, shipped filterbank
+    return f->nfeat == ST_H + NMFCC && f->cfg.use_delta_delta && f->kind == 1 && x3;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
     if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
@@ -1057,7 +1216,10 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         else
             hipLaunchKernelGGL((featurize_kernel<false, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
                                f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct);
-    } else if (stem && stem->x3)
+    } else if (stem && stem->x3 && f->cfg.use_delta_delta)
+        hipLaunchKernelGGL((featurize_kernel<false, 2, false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
+    else if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
                            f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
     else if (stem)

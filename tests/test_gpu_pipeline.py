@@ -130,3 +130,32 @@ def test_reference_default_constructor_gives_nan_logits_as_the_reference_does(re
     assert feats.shape == (6, 110, 101) and torch.isnan(feats[:, 103:]).all() and torch.isfinite(feats[:, :103]).all()
     assert torch.isnan(ref).all() and torch.isnan(logits).all() and torch.isnan(model(feats.unsqueeze(1))).all()
     assert torch.isnan(probs).all() and int(preds.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_delta_delta_pipeline_keeps_the_stem_fused_in_two_halves(resnet_heights_golden, normalize):
+    """the 103-row image of the reference's delta-delta flag (src/preprocessing.py:43-49, :471-474) no longer
+    leaves the CU -- the split-bf16 stem runs inside the featurise kernel, in two halves of 13 pooled rows.  Logits are
+    bit-identical to featurise -> classify (same images, same MFMA sequence per output), within 1e-3 of the CPU oracle, the
+    optional feature output is still the full image, and a NaN sample still gives NaN logits for that clip only."""
+    sd, _ = resnet_heights_golden["h103"]
+    kw = {**SHIPPED, "use_delta_delta": True}
+    pre = cda.AudioPreprocessor(device="cuda", **kw)
+    model = cda.create_model("residual", n_mels=103, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    model.cuda().eval()
+    pipe = cda.CoughPipeline(pre, model)
+    w = synth_batch(1200, 70, peak_normalize=False) * 0.7
+    logits, feats = pipe(w.cuda(), normalize=normalize, return_features=True)
+    direct = pre.featurize_batch(w.cuda(), normalize=normalize)
+    assert torch.equal(feats, direct)
+    assert torch.equal(logits, model(direct[:, None]))                     # bit-identical to the two-step path
+    assert torch.equal(pipe(w.cuda(), normalize=normalize), logits)       # ... and without materialised features
+    ref = ores.forward(ofeat.extract_features_batch(w, normalize_first=normalize, **kw).unsqueeze(1), sd)
+    err = (logits.cpu() - ref).abs().max().item()
+    print(f"103-row fused pipeline normalize={normalize}: logits max abs err {err:.2e}")
+    assert err < LOGIT_TOL and torch.equal(logits.cpu().argmax(1), ref.argmax(1))
+    bad = w.clone()
+    bad[3, 5000] = float("nan")
+    lb = pipe(bad.cuda(), normalize=normalize).cpu()
+    assert torch.isnan(lb[3]).all() and torch.equal(lb[[0, 1, 2, 4, 69]], logits.cpu()[[0, 1, 2, 4, 69]])
