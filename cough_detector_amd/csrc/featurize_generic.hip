@@ -1,6 +1,6 @@
 // Generic-geometry featuriser for gfx950: every AudioPreprocessor constructor geometry at n_fft = 512 that the tuned
 // one-kernel path (featurize.hip: 16 kHz, hop 160, win 400, 64 mel bands of <= 8 taps below bin 128, 13 MFCC, 1 s) does
-// not cover -- any sample_rate / hop_length / win_length <= 512 / n_mels <= 128 / n_mfcc <= n_mels / f_min / f_max
+// not cover -- any sample_rate / hop_length / win_length <= 512 / n_mels <= 256 / n_mfcc <= n_mels / f_min / f_max
 // (dense filterbanks, bins up to 256) / segment_duration (any frame count), with every flag of the constructor.
 //
 // Replaces, for those geometries, AudioPreprocessor.__init__ / extract_features / normalize
@@ -37,7 +37,7 @@ constexpr int G_NFFT = 512, G_NFREQ = 257, G_PADL = 256;
 constexpr int G_XROW = 17, G_XFRAME = 16 * G_XROW;
 constexpr int G_FPB = 16;        // frames per gen_stft workgroup: 4 waves x 4 frames
 constexpr int G_TT = 64;         // frames per workgroup of the per-frame kernels (lane = frame)
-constexpr int G_MAX_MELS = 128;
+constexpr int G_MAX_MELS = 256;   // gen_rows_kernel's dB tile is n_mels x 64 frames of dynamic LDS: 64 KB at 256 bands
 constexpr int G_CT_BINS = 128;   // spectral-contrast bands up to this many bins fill the 32 KB tile with 64 frames (wider: fewer frames)
 constexpr size_t G_SUB_BYTES = size_t(192) << 20;   // intermediates of one sub-batch: inside the 256 MiB Infinity Cache
 
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void gen_rows_kernel(const float* __restrict__
                                                        int pcen, const float* __restrict__ stat,
                                                        const float* __restrict__ dct_t /* [n_mfcc][n_mels] */,
                                                        float* __restrict__ feat, int nfeat) {
-    __shared__ float dbt[G_MAX_MELS * G_TT];
+    extern __shared__ float dbt[];   // [n_mels][G_TT] floored dB of this tile
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long clip = blockIdx.y;
     const int t = blockIdx.x * G_TT + lane;
@@ -990,7 +990,7 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, g->n_taps}, none{0, nullptr, nullptr, nullptr, nullptr, 0};
         gen_launch_stft<false, true>(g, N, T, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
-        hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), 0, stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
+        hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), size_t(n_mels) * G_TT * sizeof(float), stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
                            g->dct_t, feat, nfeat);
         if (cfg.use_mfcc) {
             hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, n_mels, n_mfcc);

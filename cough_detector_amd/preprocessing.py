@@ -15,7 +15,7 @@ Differences a caller can observe:
   through the same handle (the length is a launch parameter).
 * Every flag of the reference constructor is implemented (pre-emphasis, delta-delta, PCEN, ``use_mfcc``,
   spectral contrast + centroid) for every geometry with ``n_fft`` in 16..2048: any ``sample_rate`` /
-  ``hop_length`` / ``win_length`` / ``n_mels <= 128`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The
+  ``hop_length`` / ``win_length`` / ``n_mels <= 256`` / ``n_mfcc`` / ``f_min`` / ``f_max`` / ``segment_duration``.  The
   shipped geometry runs on the tuned one-launch kernel, the others on a chain of small kernels
   (``csrc/featurize_generic.hip``); ``n_fft`` > 2048 raises ``ValueError``.
 * ``use_spectral_contrast=True`` with 5 or more bands (the constructor default is 6) yields NaN rows exactly as
@@ -112,8 +112,8 @@ class AudioPreprocessor:
             raise ValueError(f"AudioPreprocessor: win_length={win_length} must lie in 1..n_fft (torch.stft)")
         if hop_length < 1:
             raise ValueError(f"AudioPreprocessor: hop_length={hop_length} must be positive")
-        if not 1 <= n_mels <= 128:
-            raise ValueError(f"AudioPreprocessor: n_mels={n_mels}: the MI355X path takes 1..128 mel bands")
+        if not 1 <= n_mels <= 256:
+            raise ValueError(f"AudioPreprocessor: n_mels={n_mels}: the MI355X path takes 1..256 mel bands")
         if use_mfcc and not 1 <= n_mfcc <= n_mels:
             raise ValueError("Cannot select more MFCC coefficients than # mel bins")          # torchaudio.transforms.MFCC
         if self.segment_samples <= n_fft // 2:

@@ -48,7 +48,7 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
  * Replaces AudioPreprocessor.__init__ / extract_features / normalize
  * (/root/reference/src/preprocessing.py:32-144, :432-489, :199-212) for every flag of the
  * constructor (the shipped set is /root/reference/src/train.py:264-287) and every geometry with
- * 16 <= n_fft <= 2048 (even or odd): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 128,
+ * 16 <= n_fft <= 2048 (even or odd): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 256,
  * n_mfcc <= n_mels, any filterbank (f_min / f_max), any segment longer than n_fft / 2 samples (RealtimePreprocessor's
  * window_duration, :559-580; the engine's re-construction from a checkpoint config,
  * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry,

@@ -120,6 +120,7 @@ GEOMETRIES = {     # AudioPreprocessor(...) constructor calls the generic HIP pa
     "nfft2048_sr44100": dict(n_fft=2048, win_length=2048, hop_length=512, sample_rate=44100, f_max=16000.0, n_mels=128),
     "nfft400_torchaudio_default": dict(n_fft=400, win_length=400, hop_length=200),
     "nfft301_odd": dict(n_fft=301, win_length=200, hop_length=100, n_mels=40),
+    "mels256_nfft1024": dict(n_mels=256, n_mfcc=40, n_fft=1024, win_length=1024, hop_length=256, f_min=0.0, f_max=8000.0),
 }
 
 
@@ -130,7 +131,8 @@ def geometry_clip(seed: int, n: int) -> np.ndarray:
 
 
 @pytest.mark.parametrize("name", ["mels40_fmax8k", "mels80_mfcc20", "mels128_mfcc40_fmin20", "half_second", "two_seconds",
-                                  "hop128_win512", "nfft256", "nfft1024_win400", "nfft2048_sr44100", "nfft400_torchaudio_default"])
+                                  "hop128_win512", "nfft256", "nfft1024_win400", "nfft2048_sr44100", "nfft400_torchaudio_default",
+                                  "mels256_nfft1024"])
 def test_generic_geometry_restatement_against_third_party_code(name):
     """The restatement at the constructor's OTHER geometries against transformers + scipy (code the builder did not write):
     the parameters n_mels / n_mfcc / f_min / f_max / hop / win / segment length are honoured the way independent code
