@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
             fb0 = a.fcb[0]; fb1 = a.fcb[1];
         }
     }
+    int nan_clip = 0;   // NaN rule (nn_common.h): the verdict on this thread's clip, fetched here so that its latency is long gone
+    if constexpr (COUT == 128) {
+        if (a.fcw != nullptr && a.nanflag != nullptr && (tid & 127) == 0 && (tid >> 7) < nvalid) nan_clip = a.nanflag[clip0 + (tid >> 7)];
+    }
 
     // ---- per-lane geometry: lane r owns output pixel R of each of its tiles ---------------------------------
     int goh[MW], gow[MW], px1[MW], ph1[MW];
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void resblock_x3_kernel(RbxArgs a) {
                 l0 = hred[w0 * 2] + hred[(w0 + 1) * 2] + fb0;
                 l1 = hred[w0 * 2 + 1] + hred[(w0 + 1) * 2 + 1] + fb1;
                 const long long b = clip0 + g;
-                if (a.nanflag != nullptr && a.nanflag[b]) l0 = l1 = __builtin_nanf("");   // probs NaN, argmax 0 as torch.argmax
+                if (nan_clip) l0 = l1 = __builtin_nanf("");   // probs NaN, argmax 0 as torch.argmax
                 a.logits[b * 2] = l0;
                 a.logits[b * 2 + 1] = l1;
                 if (a.probs) {

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from .pipeline import CoughPipeline
-from .preprocessing import AudioPreprocessor, RecentLog
+from .preprocessing import AudioPreprocessor
 
 SHIPPED_FLAGS = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 
@@ -64,9 +64,15 @@ class MultiStreamDetector:
         self.history = [deque(maxlen=smoothing_window) for _ in range(n_streams)]
         self.last_detection = np.zeros(n_streams, dtype=np.float64)
         self.clock = clock or (lambda: __import__("time").time())
-        # the most recent per-window probabilities of every stream (diagnostics; bounded) and the number of windows scored
-        self.window_probs: List[List[float]] = [RecentLog(prob_history) for _ in range(n_streams)]
+        # the most recent per-window probabilities of every stream (diagnostics) and the number of windows scored.  Plain lists,
+        # trimmed to `prob_history` entries once per `prob_history` appended windows (a Python-level append hook per window costs
+        # more than the GPU work of a 64-stream tick): never more than 2 x prob_history entries per stream
+        if prob_history < 1:
+            raise ValueError(f"MultiStreamDetector: prob_history={prob_history} must be positive")
+        self.prob_history = int(prob_history)
+        self.window_probs: List[List[float]] = [[] for _ in range(n_streams)]
         self.windows_seen = 0
+        self._since_trim = 0
         self._lib = _lib.load()
         self.use_graphs = use_graphs
         self._g = None            # captured steady state: dict(length, buffers, graphs)
@@ -180,7 +186,6 @@ class MultiStreamDetector:
                 continue
             conf = float(p[k])
             self.window_probs[s].append(conf)
-            self.windows_seen += 1
             h = self.history[s]
             h.append(conf)
             # np.mean of the reference (inference.py:223) adds < 8 float64 values left to right, as sum() does;
@@ -190,6 +195,13 @@ class MultiStreamDetector:
                 self.last_detection[s] = now
                 detections.append((int(s), now, smoothed))
                 fired.add(s)
+        self.windows_seen += len(w_ids)
+        self._since_trim += len(w_ids)
+        if self._since_trim >= self.prob_history:        # a stream gained at most _since_trim entries since the last trim
+            self._since_trim = 0
+            for log in self.window_probs:
+                if len(log) > self.prob_history:
+                    del log[:len(log) - self.prob_history]
         return detections
 
     def push(self, chunks, stream_ids=None) -> List[Tuple[int, float, float]]:

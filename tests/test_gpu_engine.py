@@ -206,3 +206,30 @@ def test_64_streams_config4_against_per_stream_oracles():
     for i in range(0, 24000, 1600):
         det2.push(streams[:, i:i + 1600])
     assert [p[:3] for p in det2.window_probs] == [p[:3] for p in det.window_probs]
+
+
+def test_multi_stream_probability_logs_stay_bounded():
+    """a 64-stream detector running for days must not keep one float per window forever; the logs keep the
+    most recent `prob_history` values (at most twice that between trims), `windows_seen` keeps counting."""
+    from cough_detector_amd.streaming import MultiStreamDetector
+    model = cda.create_model("residual", n_mels=90, num_classes=2, in_channels=1)
+    model.load_state_dict(synth.random_state_dict(seed=5))
+    S = 3
+    det = MultiStreamDetector(model, S, confidence_threshold=2.0, clock=lambda: 0.0, prob_history=6)
+    streams = np.stack([synth.make_stream(40 + s, 12.0) for s in range(S)])
+    tail = [[] for _ in range(S)]
+    for i in range(0, streams.shape[1], 1600):
+        before = [len(p) for p in det.window_probs]
+        det.push(streams[:, i:i + 1600])
+        for s in range(S):
+            assert len(det.window_probs[s]) <= 2 * 6 + 1
+            if len(det.window_probs[s]) != before[s]:
+                tail[s].append(det.window_probs[s][-1])
+    assert det.windows_seen == S * 45 and all(len(t) == 45 for t in tail)          # (12 s - 1 s) / 0.25 s + 1 windows per stream
+    for s in range(S):
+        n = len(det.window_probs[s])
+        assert 6 <= n <= 12 and list(det.window_probs[s]) == tail[s][-n:]
+    with pytest.raises(ValueError, match="prob_history"):
+        MultiStreamDetector(model, S, prob_history=0)
+    with pytest.raises(ValueError, match="hop_duration"):
+        MultiStreamDetector(model, S, hop_duration=0.0)
