@@ -68,7 +68,7 @@ def measured_pmc(batch: int, variant: str) -> dict:
     collected from inside this process, so the figures are read from profiles/ and only used when the batch matches.
     ``variant``: "k1" (featurise alone), "k1_fused_bf16_approx" or "k1_fused_bf16x3"."""
     names = {"k1": ["r01_k1_pmc.json"], "k1_fused_bf16_approx": ["r01_k1_fused_pmc.json"],
-             "k1_fused_bf16x3": ["r04_k1_fused_x3_pmc.json", "r03_k1_fused_x3_pmc.json", "r02_k1_fused_x3_pmc.json"]}[variant]
+             "k1_fused_bf16x3": ["r05_k1_fused_x3_pmc.json", "r04_k1_fused_x3_pmc.json", "r03_k1_fused_x3_pmc.json", "r02_k1_fused_x3_pmc.json"]}[variant]
     for name in names:                                   # newest record first
         path = os.path.join(ROOT, "profiles", name)
         try:
@@ -212,7 +212,7 @@ def stft_stage(pre, batches, launches: int = 210, warm: int = 60) -> dict:
     ms = e0.elapsed_time(e1) / launches
     achieved = b * BYTES_PER_CLIP_STFT / (ms * 1e-3) / 1e9
     traffic, src = None, None
-    for name in ("r04_stft_pmc.json", "r03_stft_pmc.json"):   # committed rocprofv3 PMC record of the same kernel, newest first
+    for name in ("r05_stft_pmc.json", "r04_stft_pmc.json", "r03_stft_pmc.json"):   # committed rocprofv3 PMC record of the same kernel, newest first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 p = json.load(f)

@@ -112,6 +112,48 @@ def test_two_threads_share_immutable_handles_on_separate_streams():
     assert results == [True, True]
 
 
+@pytest.mark.parametrize("kw", [dict(hop_length=200, n_mels=40), dict(use_spectral_contrast=True, n_contrast_bands=4),
+                                dict(f_max=8000.0, n_mels=80, n_mfcc=20)],
+                         ids=["generic_chain", "contrast_rows", "fullband"])
+def test_two_threads_share_one_preprocessor_that_needs_scratch(kw):
+    """the generic chain and the contrast rows need a workspace; one AudioPreprocessor shared by two threads on two
+    streams must give each launch scratch of its own (keyed by stream) -- every result bit-identical to the serial one, and a
+    waveform of another length in between (the same handle: the length is a launch parameter)."""
+    flags = {**SHIPPED, **{k: v for k, v in kw.items() if k.startswith("use_") or k == "n_contrast_bands"}}
+    geom = {k: v for k, v in kw.items() if k not in flags}
+    pre = cda.AudioPreprocessor(device="cuda", **geom, **flags)
+    batches = [synth_batch(8000 + 500 * k, 200 + 33 * k, peak_normalize=False).cuda() for k in range(2)]
+    odd = [b[:, :12000 + 1000 * k].contiguous() for k, b in enumerate(batches)]
+    serial = [pre.featurize_batch(b, normalize=True).clone() for b in batches]
+    serial_odd = [pre.featurize_batch(b, normalize=True).clone() for b in odd]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            start.wait()
+            with torch.cuda.stream(s):
+                ok = True
+                for it in range(30):
+                    ok &= bool(torch.equal(pre.featurize_batch(batches[k], normalize=True), serial[k]))
+                    if it % 5 == 0:
+                        ok &= bool(torch.equal(pre.featurize_batch(odd[k], normalize=True), serial_odd[k]))
+            s.synchronize()
+            results[k] = ok
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert results == [True, True] and len(pre._ws) >= 2        # one scratch buffer per stream
+
+
 def test_realtime_queue_detector_is_the_reference_consumer_loop(tmp_path):
     """cough_detector_amd.RealtimeQueueDetector = RealtimeMicrophoneDetector (/root/reference/src/inference.py:250-430) minus
     the audio back-ends: `feed` is the audio callback, `start` / `stop` / `on_detection` as in the reference.  Same stream,
