@@ -175,7 +175,8 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
     1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem, FullBank fbk,
-    const float* __restrict__ full_dct /* = fbk.dct: read-only for the kernel's lifetime, so its wave-uniform loads are scalar */) {
+    const float* __restrict__ full_dct /* = fbk.dct: read-only for the kernel's lifetime, so its wave-uniform loads are scalar */,
+    float* __restrict__ peak_out /* [n] or nullptr: the clip's max |sample| under the fused normalise (the contrast path's scale) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nmel = FULL ? fbk.n_mels : NMEL, nmfcc = FULL ? fbk.n_mfcc : NMFCC, nmf = nmfcc * NFRAMES;
     const size_t lds_mel = FULL ? full_mel_bytes(nmel) : LDS_MEL;
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // ---------------- P2: top_db floor, mel rows, DCT, z-score, deltas ----------------
     if (normalize) {
         peak_m = block_max(peak, red, tid);
+        if (peak_out != nullptr && tid == 0) peak_out[clip] = peak_m;
         // Peak normalisation is applied as a shift in dB, which needs the power of the RAW samples to be representable: a clip
         // whose peak lies outside 2^-50 .. 2^50 (never audio) is transformed again with the window taps scaled by a power of
         // two (exact), so that the reference's `waveform / max` (preprocessing.py:209-212) holds for denormal and huge peaks too
@@ -1206,31 +1208,38 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const dim3 grid(n_clips), block(THREADS);
     const StemFuse none{nullptr, nullptr, nullptr, 0, nullptr};
     const FullBank nofb{};
+    // spectral-contrast rows under the fused normalise: the featurise kernel leaves every clip's peak for the contrast path
+    float* peak_out = nullptr;
+    if (f->contrast.n_bands > 0 && norm) {
+        COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
+                      "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
+        peak_out = contrast_peaks(d_workspace, n_clips);
+    }
     if (f->kind == 2) {   // full-band instantiations: CSR filterbank in LDS, run-time n_mels / n_mfcc
         if (stem)
             hipLaunchKernelGGL((featurize_kernel<false, 2, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, f->full, f->full.dct);
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, f->full, f->full.dct, peak_out);
         else if (f->cfg.use_pre_emphasis)
             hipLaunchKernelGGL((featurize_kernel<true, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct);
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct, peak_out);
         else
             hipLaunchKernelGGL((featurize_kernel<false, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct);
+                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct, peak_out);
     } else if (stem && stem->x3 && f->cfg.use_delta_delta)
         hipLaunchKernelGGL((featurize_kernel<false, 2, false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
     else if (stem && stem->x3)
         hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
     else if (stem)
         hipLaunchKernelGGL((featurize_kernel<false, 1>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
     else if (f->cfg.use_pre_emphasis)
         hipLaunchKernelGGL((featurize_kernel<true, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr, peak_out);
     else
         hipLaunchKernelGGL((featurize_kernel<false, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr);
+                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr, peak_out);
     COUGH_HIP_CHECK(hipGetLastError());
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)
         return launch_contrast(featurizer_stft_view(f), f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase,

@@ -43,6 +43,7 @@ struct ContrastCfg {
     int edges[18];
 };
 size_t contrast_workspace_bytes(int n_clips);
+float* contrast_peaks(void* d_workspace, int n_clips);   // [n_clips] inside that workspace: per-clip max |sample| (written by K1)
 int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
                     int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
                     hipStream_t stream);

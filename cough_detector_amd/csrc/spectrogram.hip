@@ -72,8 +72,7 @@ constexpr int IMG_PIECES = (IMG + 3 + 3) / 4;                           // 16-by
 constexpr size_t LDS3_IMG = size_t(IMG_PIECES) * 16;                    // 103 840
 constexpr size_t LDS3_XCH = size_t(W3) * X3WAVE * 4;                    // 54 080
 constexpr size_t LDS3_WIN = size_t(NFFT) * 4;                           // 2 048
-constexpr size_t LDS3_PK = 128;                                         // 2 x 13 wave maxima (per-clip peak, by clip parity)
-constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN + LDS3_PK;  // 162 272
+constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN;  // 162 144
 static_assert(LDS3_TOTAL <= 160 * 1024, "one workgroup owns the CU's LDS");
 static_assert(W3 * 2 == NGROUP, "13 waves x 2 rounds = 26 groups");
 static_assert(GSPAN <= X3WAVE && GSPAN % 4 == 0, "a group's samples land in the wave's transpose scratch");
@@ -111,19 +110,32 @@ __device__ __forceinline__ void lds_barrier() {   // LDS hand-off between waves;
 // 8000 over its 16 lanes and `out` is [n_clips][101] (torchaudio.functional.spectral_centroid / (sample_rate / 2),
 // /root/reference/src/preprocessing.py:295-298, with FULLWIN + MAG).  VMW: flush-store instructions every wave is guaranteed to
 // issue behind its DMA (the counted wait below); 7 for the whole image, less when only the first `rows_out` bins are flushed
-// (the contrast path needs the bins below its last band edge; VMW = 7 always flushes all 257).  PEAK: also write max |sample| per clip.
+// (the contrast path needs the bins below its last band edge; VMW = 7 always flushes all 257).  PEAK: `peaks` [n_clips] holds every
+// clip's max |sample| (left by the featurise kernel under the fused normalise, else nullptr): a clip whose peak lies outside
+// 2^+-50 is transformed with its samples scaled by a power of two (exact), so that its power neither underflows nor overflows
+// before contrast_kernel applies 1 / peak^2 -- the reference divides the samples by the peak first (:199-212).
+// 2^k that brings a peak outside 2^-50 .. 2^50 to about 2^+-40 (exact in float32 as a factor), 1 for ordinary, zero or
+// non-finite peaks
+__device__ __forceinline__ float extreme_peak_scale(float m) {
+    const int pe = (__float_as_int(m) >> 23) & 0xff;
+    if ((pe >= 127 - 50 && pe <= 127 + 50) || m == 0.f || pe == 255) return 1.0f;
+    const int e = pe ? pe - 127 : -127 - __builtin_clz(__float_as_int(m) << 9);   // floor(log2(m))
+    int k = (e > 0 ? 40 : -40) - e;
+    k = k > 126 ? 126 : k;   // one finite factor: a denormal peak below 2^-166 + 40 cannot occur (2^-149 is the smallest)
+    return __int_as_float((127 + k) << 23);
+}
+
 template <bool FULLWIN, bool MAG, bool CENT = false, int VMW = 7, bool PEAK = false>
 __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict__ wav, long long wav_stride,
                                                          float* __restrict__ out, const float* __restrict__ win,
                                                          const float2* __restrict__ tw256,
                                                          const float2* __restrict__ tw512, int n_clips, int rows_out,
-                                                         float* __restrict__ peaks) {
+                                                         const float* __restrict__ peaks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* img0 = reinterpret_cast<float*>(smem);                                       // the clip's image (+ lead-in)
     float* xs = reinterpret_cast<float*>(smem + LDS3_IMG);                              // [W3][X3WAVE]
     float2* twl = reinterpret_cast<float2*>(smem + LDS3_IMG + LDS3_XCH);                // [16][XROW]
     float* winl = reinterpret_cast<float*>(smem + LDS3_IMG + LDS3_XCH + LDS_TW);        // [512]
-    float* pkred = reinterpret_cast<float*>(smem + LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN);   // [2][W3] wave maxima of |sample|
     constexpr int N0 = FULLWIN ? 0 : 1, N1 = FULLWIN ? 16 : 15;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,7 +192,6 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
 #endif
 
     bool first = true;
-    [[maybe_unused]] int parity = 0;
     while (true) {
         STFT3_STAMP(0);
         const long long clip_n = clip + gridDim.x;
@@ -188,6 +199,10 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
         float* oc = out + clip * (long long)(CENT ? NFRAMES : IMG);
         const int lead = CENT ? 0 : int((reinterpret_cast<size_t>(oc) >> 2) & 3);
         float* img = img0 + lead;
+        [[maybe_unused]] float cs = 1.0f;   // PEAK: power of two this clip's samples are scaled by (1 unless its peak is extreme)
+        if constexpr (PEAK) {
+            if (peaks != nullptr) cs = extreme_peak_scale(peaks[clip]);
+        }
 #pragma unroll 1
         for (int rd = 0; rd < 2; ++rd) {
             const int g = wave + W3 * rd;
@@ -211,21 +226,12 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             }
             const float* sp = myw + HOP * fsub + 2 * j;
             const float* wp = winl + 2 * j;
-            [[maybe_unused]] float gp = 0.f;   // PEAK: max |sample| under this group's live window taps
 #pragma unroll
             for (int n1 = N0; n1 < N1; ++n1) {
                 const float2 r = *reinterpret_cast<const float2*>(sp + 32 * n1);
                 const float2 w = *reinterpret_cast<const float2*>(wp + 32 * n1);
-                a[n1] = make_float2(r.x * w.x, r.y * w.y);
-                if constexpr (PEAK) gp = fmaxf(gp, fmaxf(fabsf(r.x), fabsf(r.y)));
-            }
-            if constexpr (PEAK) {
-                // the wave's running maximum lives in LDS (a register held across the clip spilled: the kernel sits at 128 VGPRs);
-                // two slots by clip parity -- a wave runs at most one clip ahead of the thread that combines them
-                if (FPW * g + fsub >= NFRAMES) gp = 0.f;   // idle sub-frames of the last group hold stale samples
-                gp = wave_max(gp);
-                float* slot = pkred + W3 * (parity & 1) + wave;
-                if (lane == 0) *slot = rd == 0 ? gp : fmaxf(*slot, gp);
+                if constexpr (PEAK) a[n1] = make_float2((r.x * cs) * w.x, (r.y * cs) * w.y);
+                else a[n1] = make_float2(r.x * w.x, r.y * w.y);
             }
             wave_lds_fence();
             dft16(a);
@@ -314,16 +320,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
         }
         STFT3_STAMP(5);
         if constexpr (!CENT) lds_barrier();
-        if constexpr (PEAK) {   // per-clip peak of normalize() (:199-212): the waves' maxima, combined behind the barrier
-            if (tid == 0) {
-                const float* slot = pkred + W3 * (parity & 1);
-                float m = slot[0];
-#pragma unroll
-                for (int w = 1; w < W3; ++w) m = fmaxf(m, slot[w]);
-                peaks[clip] = m;
-            }
-            ++parity;
-        }
+
         STFT3_STAMP(6);
 #ifndef COUGH_STFT_NO_STORE
         if constexpr (!CENT) {
@@ -434,8 +431,8 @@ __global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __res
     float scale = 1.0f;
     if (normalize) {
         const float m = peaks[clip];
-        if (m > 0.f) {
-            const float inv = 1.0f / m;
+        if (m > 0.f) {   // the power rows are those of samples * extreme_peak_scale(m): divide by (m * that)^2
+            const float inv = 1.0f / (m * extreme_peak_scale(m));
             scale = inv * inv;
         }
     }
@@ -494,13 +491,16 @@ CtCarve ct_carve(int n_clips) {
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     c.o_cent = al(c.sub * NFREQ * NFRAMES * sizeof(float));
     c.o_peak = c.o_cent + al(c.sub * NFRAMES * sizeof(float));
-    c.total = c.o_peak + al(c.sub * sizeof(float));
+    c.total = c.o_peak + al(size_t(n_clips) * sizeof(float));   // peaks: every clip of the call (the featurise kernel writes them)
     return c;
 }
 
 }  // namespace
 
 size_t contrast_workspace_bytes(int n_clips) { return ct_carve(n_clips).total; }
+float* contrast_peaks(void* d_workspace, int n_clips) {
+    return reinterpret_cast<float*>(static_cast<char*>(d_workspace) + ct_carve(n_clips).o_peak);
+}
 
 int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wav, long long wav_stride, float* d_feat,
                     int nfeat, int row0, int n_clips, int normalize, void* d_workspace, size_t workspace_bytes,
@@ -527,19 +527,20 @@ int launch_contrast(const StftView& v, const ContrastCfg& cfg, const float* d_wa
         const int nc = n_clips - c0 < int(c.sub) ? n_clips - c0 : int(c.sub);
         const float* w = d_wav + (long long)c0 * wav_stride;
         const dim3 grid3(nc < v.n_cus ? nc : v.n_cus), block3(THREADS3);
-        float* pk = normalize ? peaks : nullptr;
-        (void)pk;
+        const float* pk = normalize ? peaks + c0 : nullptr;   // left by the featurise kernel (launch_featurize)
 #define COUGH_STFT_POWER(V) hipLaunchKernelGGL((stft3_kernel<false, false, false, V, true>), grid3, block3, LDS3_TOTAL, stream, w, \
-                                               wav_stride, pw, v.win, v.tw256, v.tw512, nc, rows_out, peaks)
+                                               wav_stride, pw, v.win, v.tw256, v.tw512, nc, rows_out, pk)
         if (sure >= 7) COUGH_STFT_POWER(7);
         else if (sure >= 3) COUGH_STFT_POWER(3);
         else if (sure >= 2) COUGH_STFT_POWER(2);
         else if (sure >= 1) COUGH_STFT_POWER(1);
         else COUGH_STFT_POWER(0);
 #undef COUGH_STFT_POWER
-        hipLaunchKernelGGL((stft3_kernel<true, true, true>), grid3, block3, LDS3_TOTAL, stream, w, wav_stride, cent, v.win_full,
-                           v.tw256, v.tw512, nc, 0, static_cast<float*>(nullptr));
-        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), 0, stream, pw, cent, peaks,
+        // the centroid is a ratio of magnitudes, scale-invariant -- but sqrt(re^2 + im^2) is not safe from under- / overflow:
+        // the same power-of-two prescale of extreme clips
+        hipLaunchKernelGGL((stft3_kernel<true, true, true, 7, true>), grid3, block3, LDS3_TOTAL, stream, w, wav_stride, cent,
+                           v.win_full, v.tw256, v.tw512, nc, 0, pk);
+        hipLaunchKernelGGL(contrast_kernel, dim3(nc), dim3(CT_THREADS), 0, stream, pw, cent, pk,
                            d_feat + (long long)c0 * nfeat * NFRAMES, nfeat, row0, cfg, normalize);
         COUGH_HIP_CHECK(hipGetLastError());
     }
@@ -554,10 +555,10 @@ int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, flo
     // the > 64 KB dynamic-LDS attribute of the four instantiations is set per device by stft_prepare_device (called from
     // cough_featurizer_create on the featuriser's device), not lazily here: the attribute is per device and a launch
     // path must not carry process-wide mutable state
-    if (full && mag) hipLaunchKernelGGL((stft3_kernel<true, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
-    else if (full) hipLaunchKernelGGL((stft3_kernel<true, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
-    else if (mag) hipLaunchKernelGGL((stft3_kernel<false, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
-    else hipLaunchKernelGGL((stft3_kernel<false, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<float*>(nullptr));
+    if (full && mag) hipLaunchKernelGGL((stft3_kernel<true, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<const float*>(nullptr));
+    else if (full) hipLaunchKernelGGL((stft3_kernel<true, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<const float*>(nullptr));
+    else if (mag) hipLaunchKernelGGL((stft3_kernel<false, true>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<const float*>(nullptr));
+    else hipLaunchKernelGGL((stft3_kernel<false, false>), grid3, block3, LDS3_TOTAL, stream, d_wav, wav_stride, d_spec, win, v.tw256, v.tw512, n_clips, NFREQ, static_cast<const float*>(nullptr));
     COUGH_HIP_CHECK(hipGetLastError());
     return COUGH_OK;
 }
@@ -574,7 +575,7 @@ int stft_prepare_device(int* n_cus) {
                          reinterpret_cast<const void*>(stft3_kernel<false, false, false, 2, true>),
                          reinterpret_cast<const void*>(stft3_kernel<false, false, false, 1, true>),
                          reinterpret_cast<const void*>(stft3_kernel<false, false, false, 0, true>),
-                         reinterpret_cast<const void*>(stft3_kernel<true, true, true>)};
+                         reinterpret_cast<const void*>(stft3_kernel<true, true, true, 7, true>)};
     for (const void* fn : fns)
         COUGH_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS3_TOTAL));
     return COUGH_OK;

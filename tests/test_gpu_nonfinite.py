@@ -160,3 +160,25 @@ def test_engine_keeps_a_nan_in_its_smoothing_history_like_the_reference(tmp_path
     ok = ~np.isnan(want)
     assert np.abs(got[ok] - want[ok]).max() < 1e-3
     assert events == ref_events and any(events)
+
+
+@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_hop200_40mel"])
+def test_contrast_rows_of_extreme_peak_clips_under_normalize(geo):
+    """The spectral-contrast rows come from a second STFT of the un-emphasised signal; with `normalize` the reference has divided
+    by the peak first (:199-212, :476-478), so a denormal or huge clip gives the rows of the same clip at unit peak.  The tuned
+    path's power pass scales such a clip's samples by a power of two (the featurise kernel leaves every clip's peak)."""
+    flags = {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 4}
+    pre = cda.AudioPreprocessor(device="cuda", **flags, **GEOMETRIES[geo])
+    base = synth_batch(345, 1, peak_normalize=True)[0]
+    scales = [1e-42, 1e-30, 1e-19, 1e-3, 1.0, 1e19, 1e30]
+    w = torch.stack([(base.double() * s).float() for s in scales])
+    got = pre.featurize_batch(w.cuda(), normalize=True).cpu()
+    ref = _oracle(w, True, GEOMETRIES[geo], **flags)
+    assert got.shape == ref.shape and torch.isfinite(ref).all()
+    nb = got.shape[1] - 5
+    err_rows = (got[:, nb:] - ref[:, nb:]).abs().amax(dim=(1, 2))
+    err_front = (got[:, :nb] - ref[:, :nb]).abs().max().item()
+    print(f"{geo}: contrast rows of extreme-peak clips: per clip {[float('%.1e' % e) for e in err_rows]}, rows in front {err_front:.1e}")
+    assert err_front < 1e-4
+    assert err_rows[1:].max().item() < 5e-5          # 1e-30 .. 1e30
+    assert err_rows[0].item() < 5e-2                 # 1e-42: the samples themselves keep ~9 bits (712 denormal steps)
