@@ -269,204 +269,203 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // P1 as a body that can run twice: once for every clip, and a second time -- window taps scaled by a power of two -- for a
     // clip whose peak lies outside 2^-50 .. 2^50 under the fused normalise (never audio; see below)
     auto p1_pass = [&](const float ws1, const float ws2) {
-    float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
-    const int jw = 2 * j;
+        float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
+        const int jw = 2 * j;
 #pragma unroll
-    for (int n1 = 1; n1 < 15; ++n1) {
-        w_re[n1] = tb->win[32 * n1 + jw] * ws1 * ws2;
-        w_im[n1] = tb->win[32 * n1 + jw + 1] * ws1 * ws2;
-    }
-    load_group(wave, raw);
-
-    K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
-    for (int g = wave; g < NGROUP; g += WAVES) {
-        K1_MARK("PHASE P1 peak + window multiply + next group's loads");
-        const int t_raw = FPW * g + fsub;
-        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
-        const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
-        float2 a[16];
-        a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
-        a[15] = make_float2(0.f, 0.f);
-        if constexpr (!PRE_EMPH) {
-#pragma unroll
-            for (int n1 = 1; n1 < 15; ++n1) {
-                peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));   // one v_max3_f32 with |.| modifiers
-                a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
-            }
+        for (int n1 = 1; n1 < 15; ++n1) {
+            w_re[n1] = tb->win[32 * n1 + jw] * ws1 * ws2;
+            w_im[n1] = tb->win[32 * n1 + jw + 1] * ws1 * ws2;
         }
-        if constexpr (PRE_EMPH) {
-            // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the reflect padding as the
-            // reference does; no FMA contraction (mul_rn, __fsub_rn).  The peak is of x, not of the emphasised signal.
-            if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
-                // x[i0 - 1] is the second sample of the lane to the left (row_ror:1); lane 0 takes lane 15's pair of the
-                // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does)
-                float carry = 0.f;
+        load_group(wave, raw);
+
+        K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
+        for (int g = wave; g < NGROUP; g += WAVES) {
+            K1_MARK("PHASE P1 peak + window multiply + next group's loads");
+            const int t_raw = FPW * g + fsub;
+            const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
+            const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
+            float2 a[16];
+            a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
+            a[15] = make_float2(0.f, 0.f);
+            if constexpr (!PRE_EMPH) {
 #pragma unroll
                 for (int n1 = 1; n1 < 15; ++n1) {
-                    const float rot = dpp_mov<0x121>(raw[n1].y);
-                    const float left = j == 0 ? carry : rot;
-                    carry = rot;
-                    const float x0 = raw[n1].x, x1 = raw[n1].y;
-                    peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
-                    a[n1] = make_float2(__fsub_rn(x0, mul_rn(pre_coef, left)) * w_re[n1],
-                                        __fsub_rn(x1, mul_rn(pre_coef, x0)) * w_im[n1]);
-                }
-            } else {   // reflected edge frames (3 of 26 groups): the left neighbour in CLIP order, by re-gather
-#pragma unroll
-                for (int n1 = 1; n1 < 15; ++n1) {
-                    int i0 = s0 + 32 * n1, i1 = i0 + 1;
-                    i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
-                    i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
-                    const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
-                    const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
-                    const float x0 = raw[n1].x, x1 = raw[n1].y;
-                    peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
-                    a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
+                    peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));   // one v_max3_f32 with |.| modifiers
+                    a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
                 }
             }
-        }
-        // the raw registers are free again: the next group's samples start moving now and land while
-        // this group's FFT / mel / log run
-        if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
-        K1_MARK("PHASE P1 radix-16 #1");
-        dft16(a);
-        K1_MARK("PHASE P1 twiddle (LDS table) complex multiply");
+            if constexpr (PRE_EMPH) {
+                // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the reflect padding as the
+                // reference does; no FMA contraction (mul_rn, __fsub_rn).  The peak is of x, not of the emphasised signal.
+                if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
+                    // x[i0 - 1] is the second sample of the lane to the left (row_ror:1); lane 0 takes lane 15's pair of the
+                    // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does)
+                    float carry = 0.f;
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
-        K1_MARK("PHASE P1 16x16 transpose through LDS");
-        // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
-        float2 z[16];
+                    for (int n1 = 1; n1 < 15; ++n1) {
+                        const float rot = dpp_mov<0x121>(raw[n1].y);
+                        const float left = j == 0 ? carry : rot;
+                        carry = rot;
+                        const float x0 = raw[n1].x, x1 = raw[n1].y;
+                        peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
+                        a[n1] = make_float2(__fsub_rn(x0, mul_rn(pre_coef, left)) * w_re[n1],
+                                            __fsub_rn(x1, mul_rn(pre_coef, x0)) * w_im[n1]);
+                    }
+                } else {   // reflected edge frames (3 of 26 groups): the left neighbour in CLIP order, by re-gather
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].x;
-        wave_lds_fence();
+                    for (int n1 = 1; n1 < 15; ++n1) {
+                        int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                        i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
+                        i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                        const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
+                        const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
+                        const float x0 = raw[n1].x, x1 = raw[n1].y;
+                        peak = fmaxf(peak, fmaxf(fabsf(x0), fabsf(x1)));
+                        a[n1] = make_float2(__fsub_rn(x0, p0) * w_re[n1], __fsub_rn(x1, p1) * w_im[n1]);
+                    }
+                }
+            }
+            // the raw registers are free again: the next group's samples start moving now and land while
+            // this group's FFT / mel / log run
+            if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
+            K1_MARK("PHASE P1 radix-16 #1");
+            dft16(a);
+            K1_MARK("PHASE P1 twiddle (LDS table) complex multiply");
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) z[n2].x = FULL ? fxr[n2] : myx[j * XROW + n2];
-        wave_lds_fence();
+            for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
+            K1_MARK("PHASE P1 16x16 transpose through LDS");
+            // 16x16 transpose through LDS: real parts, then imaginary parts through the same scratch
+            float2 z[16];
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].y;
-        wave_lds_fence();
+            for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].x;
+            wave_lds_fence();
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) z[n2].y = FULL ? fxr[n2] : myx[j * XROW + n2];
-        K1_MARK("PHASE P1 radix-16 #2");
-        dft16(z);   // z[k2] = Z[j + 16*k2]
-        K1_MARK("PHASE P1 real-input split + |X|^2 -> LDS");
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].x = FULL ? fxr[n2] : myx[j * XROW + n2];
+            wave_lds_fence();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) (FULL ? fxw[k1 * FX_ROW] : myx[k1 * XROW + j]) = a[k1].y;
+            wave_lds_fence();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) z[n2].y = FULL ? fxr[n2] : myx[j * XROW + n2];
+            K1_MARK("PHASE P1 radix-16 #2");
+            dft16(z);   // z[k2] = Z[j + 16*k2]
+            K1_MARK("PHASE P1 real-input split + |X|^2 -> LDS");
 
-        // partner Z[256-k] lives in lane (16-j)&15, register 15-k2 (j>=1) or 16-k2 (j==0)
-        float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror (j -> 15 - j), then rotate right by one
+            // partner Z[256-k] lives in lane (16-j)&15, register 15-k2 (j>=1) or 16-k2 (j==0)
+            float2 rv[8];   // z[8 + r] of lane (16 - j) & 15 of the same frame: row_mirror (j -> 15 - j), then rotate right by one
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
-            rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
-        }
-        wave_lds_fence();
-        if constexpr (!FULL) {
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            const float2 zk = z[k2];
-            const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
-            const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
-            // 2*X[k] = (Zk + conj Zp) - i*W512^k*(Zk - conj Zp); the factor 1/2 (1/4 in power) is folded
-            // into the mel taps at create time (exact: a power of two)
-            const float ex = zk.x + zp.x, ey = zk.y - zp.y;
-            const float ox = zk.y + zp.y, oy = zp.x - zk.x;
-            const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;   // W32^k2 * O
-            const float xr = ex + tw_j.x * qx - tw_j.y * qy;
-            const float xi = ey + tw_j.x * qy + tw_j.y * qx;
-            myx[j + 16 * k2] = xr * xr + xi * xi;
-        }
-        wave_lds_fence();
-        K1_MARK("PHASE P1 sparse mel + log2 -> LDS");
-        // sparse mel: lane = band, the wave's 4 frames
-#pragma unroll
-        for (int f = 0; f < FPW; ++f) {
-            const float* p = xs + (wave * FPW + f) * XFRAME + mstart;
-            float acc = 0.f;
-#pragma unroll
-            for (int q = 0; q < MAXW; ++q) acc += mw[q] * p[q];
-            const int tf = FPW * g + f;
-            if (tf < NFRAMES) {
-                // raw dB = 10*log10(acc) = 3.0103*log2(acc) on the hardware log2 (|error| ~1e-6 dB);
-                // -inf for 0: amin and normalisation are applied in P2
-                const float db = 3.01029995663981195f * __log2f(acc);
-                melbuf[lane * NFRAMES + tf] = db;
-                run_max = fmaxf(run_max, db);
-                chk = fmaf(acc, 0.f, chk);   // NaN / Inf power (a non-finite sample under the frame, f32 overflow) -> NaN, sticky
+            for (int r = 0; r < 8; ++r) {
+                rv[r].x = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].x));
+                rv[r].y = dpp_mov<0x121>(dpp_mov<0x140>(z[8 + r].y));
             }
-        }
-        } else {
-        // all 257 bins: 2X[k] = 2E + W^k 2O and 2X[256 - k] = conj(2E - W^k 2O) from the same butterfly (as spectrogram.hip);
-        // the four power rows of the wave's frames replace its transpose scratch
+            wave_lds_fence();
+            if constexpr (!FULL) {
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            const float2 zk = z[k2];
-            const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
-            const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
-            const float ex = zk.x + zp.x, ey = zk.y - zp.y;
-            const float ox = zk.y + zp.y, oy = zp.x - zk.x;
-            const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
-            const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
-            const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
-            prow[j + 16 * k2] = ar * ar + ai * ai;
-            prow[NFFT / 2 - (j + 16 * k2)] = br * br + bi * bi;
-        }
-        if (j == 0) prow[NFFT / 4] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // X[128] = conj Z[128]
-        wave_lds_fence();
-        K1_MARK("PHASE P1 CSR mel + log2 -> LDS");
-        // CSR mel: lane = band (64 bands per pass), the wave's 4 frames share every tap read; a band's taps run in ascending
-        // bin order up to the widest band of the pass (wave-uniform bound, narrower bands idle)
-        auto mel_pass = [&](auto fpl_tag, int ps) {
-            constexpr int FPL = decltype(fpl_tag)::value;   // frames per lane: 4, 2 or 1
-            const int f0 = FPL == 4 ? 0 : FPL == 2 ? 2 * (lane >> 5) : (lane >> 4);
-            const int mb = b_band[ps], wdt = mb >= 0 ? b_w[ps] : 0;
-            const float* wm = b_taps[ps];
-            const float* p0 = myw + f0 * FX_PROW + b_lo[ps];
-            float acc[FPL];
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) acc[f] = 0.f;
-            // Branch-free, two PAIRS of bins per step, every access an aligned 8-byte LDS read: a band's taps start at an even bin
-            // and have an even count (zero taps as padding, built at create time), so the taps and the four frames' powers of a bin
-            // pair are one ds_read_b64 each and the reads of a step are all in flight together.  (One tap per iteration behind a
-            // divergent branch serialised the loop on the LDS latency -- 19 round trips for the widest band of the 64-band / 8 kHz
-            // bank; 4-byte reads with clamped indices cost 100 LDS instructions per four-frame group.)  A lane past its band's end
-            // re-reads the band's last pair with weight 0: no read leaves the band.
-            const int wmax = fbk.maxw[ps];   // a multiple of 4
-            const int lastp = wdt > 2 ? wdt - 2 : 0;
-            for (int k0 = 0; k0 < wmax; k0 += 4) {
-                float2 w[2], pw[2][FPL];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int k = k0 + 2 * u, kk = k < lastp ? k : lastp;
-                    w[u] = *reinterpret_cast<const float2*>(wm + kk);
-#pragma unroll
-                    for (int f = 0; f < FPL; ++f) pw[u][f] = *reinterpret_cast<const float2*>(p0 + f * FX_PROW + kk);
-                    if (k >= wdt) w[u] = make_float2(0.f, 0.f);
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 zk = z[k2];
+                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+                    // 2*X[k] = (Zk + conj Zp) - i*W512^k*(Zk - conj Zp); the factor 1/2 (1/4 in power) is folded
+                    // into the mel taps at create time (exact: a power of two)
+                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;   // W32^k2 * O
+                    const float xr = ex + tw_j.x * qx - tw_j.y * qy;
+                    const float xi = ey + tw_j.x * qy + tw_j.y * qx;
+                    myx[j + 16 * k2] = xr * xr + xi * xi;
                 }
+                wave_lds_fence();
+                K1_MARK("PHASE P1 sparse mel + log2 -> LDS");
+                // sparse mel: lane = band, the wave's 4 frames
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int f = 0; f < FPW; ++f) {
+                    const float* p = xs + (wave * FPW + f) * XFRAME + mstart;
+                    float acc = 0.f;
 #pragma unroll
-                    for (int f = 0; f < FPL; ++f) acc[f] = fmaf(w[u].y, pw[u][f].y, fmaf(w[u].x, pw[u][f].x, acc[f]));
-            }
+                    for (int q = 0; q < MAXW; ++q) acc += mw[q] * p[q];
+                    const int tf = FPW * g + f;
+                    if (tf < NFRAMES) {
+                        // raw dB = 10*log10(acc) = 3.0103*log2(acc) on the hardware log2 (|error| ~1e-6 dB);
+                        // -inf for 0: amin and normalisation are applied in P2
+                        const float db = 3.01029995663981195f * __log2f(acc);
+                        melbuf[lane * NFRAMES + tf] = db;
+                        run_max = fmaxf(run_max, db);
+                        chk = fmaf(acc, 0.f, chk);   // NaN / Inf power (a non-finite sample under the frame, f32 overflow) -> NaN, sticky
+                    }
+                }
+            } else {
+                // all 257 bins: 2X[k] = 2E + W^k 2O and 2X[256 - k] = conj(2E - W^k 2O) from the same butterfly (as spectrogram.hip);
+                // the four power rows of the wave's frames replace its transpose scratch
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const int tf = FPW * g + f0 + f;
-                if (mb >= 0 && tf < NFRAMES) {
-                    const float db = 3.01029995663981195f * __log2f(acc[f]);   // as above
-                    melbuf[mb * NFRAMES + tf] = db;
-                    run_max = fmaxf(run_max, db);
-                    chk = fmaf(acc[f], 0.f, chk);
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float2 zk = z[k2];
+                    const float2 zp0 = (k2 == 0) ? z[0] : rv[8 - k2];   // j == 0
+                    const float2 zp = (j == 0) ? zp0 : rv[7 - k2];
+                    const float ex = zk.x + zp.x, ey = zk.y - zp.y;
+                    const float ox = zk.y + zp.y, oy = zp.x - zk.x;
+                    const float qx = W32C[k2] * ox - W32S[k2] * oy, qy = W32C[k2] * oy + W32S[k2] * ox;
+                    const float px = tw_j.x * qx - tw_j.y * qy, py = tw_j.x * qy + tw_j.y * qx;
+                    const float ar = ex + px, ai = ey + py, br = ex - px, bi = ey - py;
+                    prow[j + 16 * k2] = ar * ar + ai * ai;
+                    prow[NFFT / 2 - (j + 16 * k2)] = br * br + bi * bi;
+                }
+                if (j == 0) prow[NFFT / 4] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // X[128] = conj Z[128]
+                wave_lds_fence();
+                K1_MARK("PHASE P1 CSR mel + log2 -> LDS");
+                // CSR mel: lane = band (64 bands per pass), the wave's 4 frames share every tap read; a band's taps run in ascending
+                // bin order up to the widest band of the pass (wave-uniform bound, narrower bands idle)
+                auto mel_pass = [&](auto fpl_tag, int ps) {
+                    constexpr int FPL = decltype(fpl_tag)::value;   // frames per lane: 4, 2 or 1
+                    const int f0 = FPL == 4 ? 0 : FPL == 2 ? 2 * (lane >> 5) : (lane >> 4);
+                    const int mb = b_band[ps], wdt = mb >= 0 ? b_w[ps] : 0;
+                    const float* wm = b_taps[ps];
+                    const float* p0 = myw + f0 * FX_PROW + b_lo[ps];
+                    float acc[FPL];
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) acc[f] = 0.f;
+                    // Branch-free, two PAIRS of bins per step, every access an aligned 8-byte LDS read: a band's taps start at an even bin
+                    // and have an even count (zero taps as padding, built at create time), so the taps and the four frames' powers of a bin
+                    // pair are one ds_read_b64 each and the reads of a step are all in flight together.  (One tap per iteration behind a
+                    // divergent branch serialised the loop on the LDS latency -- 19 round trips for the widest band of the 64-band / 8 kHz
+                    // bank; 4-byte reads with clamped indices cost 100 LDS instructions per four-frame group.)  A lane past its band's end
+                    // re-reads the band's last pair with weight 0: no read leaves the band.
+                    const int wmax = fbk.maxw[ps];   // a multiple of 4
+                    const int lastp = wdt > 2 ? wdt - 2 : 0;
+                    for (int k0 = 0; k0 < wmax; k0 += 4) {
+                        float2 w[2], pw[2][FPL];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int k = k0 + 2 * u, kk = k < lastp ? k : lastp;
+                            w[u] = *reinterpret_cast<const float2*>(wm + kk);
+#pragma unroll
+                            for (int f = 0; f < FPL; ++f) pw[u][f] = *reinterpret_cast<const float2*>(p0 + f * FX_PROW + kk);
+                            if (k >= wdt) w[u] = make_float2(0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int f = 0; f < FPL; ++f) acc[f] = fmaf(w[u].y, pw[u][f].y, fmaf(w[u].x, pw[u][f].x, acc[f]));
+                    }
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) {
+                        const int tf = FPW * g + f0 + f;
+                        if (mb >= 0 && tf < NFRAMES) {
+                            const float db = 3.01029995663981195f * __log2f(acc[f]);   // as above
+                            melbuf[mb * NFRAMES + tf] = db;
+                            run_max = fmaxf(run_max, db);
+                            chk = fmaf(acc[f], 0.f, chk);
+                        }
+                    }
+                };
+                mel_pass(std::integral_constant<int, 4>{}, 0);
+                if (nmel > 64) {   // workgroup-uniform
+                    if (fpl1 == 4) mel_pass(std::integral_constant<int, 4>{}, 1);
+                    else if (fpl1 == 2) mel_pass(std::integral_constant<int, 2>{}, 1);
+                    else mel_pass(std::integral_constant<int, 1>{}, 1);
                 }
             }
-        };
-        mel_pass(std::integral_constant<int, 4>{}, 0);
-        if (nmel > 64) {   // workgroup-uniform
-            if (fpl1 == 4) mel_pass(std::integral_constant<int, 4>{}, 1);
-            else if (fpl1 == 2) mel_pass(std::integral_constant<int, 2>{}, 1);
-            else mel_pass(std::integral_constant<int, 1>{}, 1);
+            wave_lds_fence();
         }
-        }
-        wave_lds_fence();
-    }
-
     };
     p1_pass(1.f, 1.f);
 
@@ -663,7 +662,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         if constexpr (STEM == 2) img_lo[idx] = f2bf(v - __uint_as_float(uint32_t(hi) << 16));
     };
     if constexpr (TALL) {
-        static_assert(!TALL || (STEM == 2 && !FULL), "the 103-row stem: split-bf16 operands, shipped filterbank");
+        static_assert(!TALL || STEM == 2, "the 103-row stem: split-bf16 operands");
         // ---- 103-row image (delta-delta on), stem in two halves.  Half h covers pooled rows [13 h, 13 h + 13) = conv rows
         // [26 h, 26 h + 26) = image rows (feature row + 3) [52 h, 52 h + 57): half 0 is mel rows 0..53 under the top border, half 1
         // mel rows 49..63, the MFCC / delta / delta-delta rows and the bottom border.  LDS: MFCC + delta buffers (10.5 KB) | hi + lo
@@ -1124,7 +1123,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
         // more than 64 KB of dynamic LDS with many mel bands: per-device attribute, set here (not lazily at launch)
         const void* fns[] = {reinterpret_cast<const void*>(featurize_kernel<false, 0, true>),
                              reinterpret_cast<const void*>(featurize_kernel<true, 0, true>),
-                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true>)};
+                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true, false>),
+                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, false>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true>)};
         for (const void* fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
@@ -1174,13 +1176,14 @@ int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
 bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->kind != 0 && (n_samples <= 0 || n_samples == NS); }
 bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
-    if (f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->cfg.use_pre_emphasis || f->cfg.use_pcen ||
-        f->nfeat != f->nbase)
+    // a one-launch kernel writing the whole image (no contrast rows), 64 mel + 13 MFCC rows, log-mel (the PCEN rows are formed in
+    // another thread mapping than the image is built in)
+    if (f->kind == 0 || f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->cfg.use_pcen || f->nfeat != f->nbase)
         return false;
-    // the 90-row layout (64 mel + 13 MFCC + 13 delta); the full-band kernel is instantiated for the split-bf16 stem only
-    if (f->nfeat == ST_H) return f->kind == 1 || (f->kind == 2 && x3);
-    // the 103-row layout of the delta-delta flag: split-bf16 stem in two halves, shipped filterbank
-    return f->nfeat == ST_H + NMFCC && f->cfg.use_delta_delta && f->kind == 1 && x3;
+    // split-bf16 stem: the 90-row layout, or the 103-row layout of the delta-delta flag (two halves); shipped or full-band
+    // filterbank, with or without pre-emphasis.  The approximate single-bf16 stem exists for the shipped 90-row set only.
+    if (x3) return f->nfeat == ST_H || (f->nfeat == ST_H + NMFCC && f->cfg.use_delta_delta);
+    return f->nfeat == ST_H && f->kind == 1 && !f->cfg.use_pre_emphasis;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
     if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
@@ -1215,31 +1218,37 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
                       "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
         peak_out = contrast_peaks(d_workspace, n_clips);
     }
-    if (f->kind == 2) {   // full-band instantiations: CSR filterbank in LDS, run-time n_mels / n_mfcc
-        if (stem)
-            hipLaunchKernelGGL((featurize_kernel<false, 2, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, f->full, f->full.dct, peak_out);
-        else if (f->cfg.use_pre_emphasis)
-            hipLaunchKernelGGL((featurize_kernel<true, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct, peak_out);
-        else
-            hipLaunchKernelGGL((featurize_kernel<false, 0, true>), grid, block, f->full_lds, stream, d_wav, wav_stride, d_feat,
-                               f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, f->full, f->full.dct, peak_out);
-    } else if (stem && stem->x3 && f->cfg.use_delta_delta)
-        hipLaunchKernelGGL((featurize_kernel<false, 2, false, true>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
-    else if (stem && stem->x3)
-        hipLaunchKernelGGL((featurize_kernel<false, 2>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
-    else if (stem)
-        hipLaunchKernelGGL((featurize_kernel<false, 1>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, 0, *stem, nofb, nullptr, peak_out);
-    else if (f->cfg.use_pre_emphasis)
-        hipLaunchKernelGGL((featurize_kernel<true, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr, peak_out);
-    else
-        hipLaunchKernelGGL((featurize_kernel<false, 0>), grid, block, LDS_TOTAL, stream, d_wav, wav_stride, d_feat,
-                           f->nfeat, f->d_tables, norm, f->cfg.pre_emphasis_coef, rows, f->cfg.use_pcen, none, nofb, nullptr, peak_out);
+    // one instantiation per (pre-emphasis, stem, full-band filterbank, 103-row stem); everything else is a run-time argument
+    const bool full = f->kind == 2, pe = f->cfg.use_pre_emphasis != 0;
+    const size_t lds = full ? f->full_lds : LDS_TOTAL;
+    const FullBank& fbk = full ? f->full : nofb;
+    const float* fdct = full ? f->full.dct : nullptr;
+    auto go = [&](auto kernel, const StemFuse& sf, int pcen) {
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
+                           f->cfg.pre_emphasis_coef, rows, pcen, sf, fbk, fdct, peak_out);
+    };
+    if (stem && stem->x3) {   // split-bf16 stem fused (90-row image, or the 103-row image of the delta-delta flag in two halves)
+        const bool tall = f->cfg.use_delta_delta != 0;
+        const int sel = (pe ? 4 : 0) | (full ? 2 : 0) | (tall ? 1 : 0);
+        switch (sel) {
+            case 0: go(featurize_kernel<false, 2, false, false>, *stem, 0); break;
+            case 1: go(featurize_kernel<false, 2, false, true>, *stem, 0); break;
+            case 2: go(featurize_kernel<false, 2, true, false>, *stem, 0); break;
+            case 3: go(featurize_kernel<false, 2, true, true>, *stem, 0); break;
+            case 4: go(featurize_kernel<true, 2, false, false>, *stem, 0); break;
+            case 5: go(featurize_kernel<true, 2, false, true>, *stem, 0); break;
+            case 6: go(featurize_kernel<true, 2, true, false>, *stem, 0); break;
+            default: go(featurize_kernel<true, 2, true, true>, *stem, 0); break;
+        }
+    } else if (stem) {        // approximate single-bf16 stem: shipped filterbank, no pre-emphasis (featurizer_stem_fusable)
+        go(featurize_kernel<false, 1>, *stem, 0);
+    } else if (full) {
+        if (pe) go(featurize_kernel<true, 0, true>, none, f->cfg.use_pcen);
+        else go(featurize_kernel<false, 0, true>, none, f->cfg.use_pcen);
+    } else {
+        if (pe) go(featurize_kernel<true, 0>, none, f->cfg.use_pcen);
+        else go(featurize_kernel<false, 0>, none, f->cfg.use_pcen);
+    }
     COUGH_HIP_CHECK(hipGetLastError());
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)
         return launch_contrast(featurizer_stft_view(f), f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase,

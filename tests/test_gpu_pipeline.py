@@ -159,3 +159,32 @@ def test_delta_delta_pipeline_keeps_the_stem_fused_in_two_halves(resnet_heights_
     bad[3, 5000] = float("nan")
     lb = pipe(bad.cuda(), normalize=normalize).cpu()
     assert torch.isnan(lb[3]).all() and torch.equal(lb[[0, 1, 2, 4, 69]], logits.cpu()[[0, 1, 2, 4, 69]])
+
+
+@pytest.mark.parametrize("kw", [dict(use_pre_emphasis=True), dict(use_pre_emphasis=True, use_delta_delta=True),
+                                dict(f_max=8000.0, use_delta_delta=True), dict(f_max=8000.0, use_pre_emphasis=True),
+                                dict(f_max=8000.0, use_pre_emphasis=True, use_delta_delta=True)],
+                         ids=["preemph", "preemph_dd", "fullband_dd", "fullband_preemph", "fullband_preemph_dd"])
+def test_every_fused_stem_instantiation_equals_featurise_then_classify(resnet_golden, resnet_heights_golden, kw):
+    """The split-bf16 stem stays inside the featurise kernel for pre-emphasis, for any filterbank at the shipped STFT geometry and
+    for the 103-row delta-delta image, in every combination (featurize_kernel<PRE_EMPH, 2, FULL, TALL>): bit-identical to the
+    two-step path, within 1e-3 of the CPU oracle."""
+    flags = {**SHIPPED, **{k: v for k, v in kw.items() if k.startswith("use_")}}
+    geom = {k: v for k, v in kw.items() if not k.startswith("use_")}
+    rows = 103 if flags["use_delta_delta"] else 90
+    sd = resnet_heights_golden["h103"][0] if rows == 103 else resnet_golden[0]
+    pre = cda.AudioPreprocessor(device="cuda", **geom, **flags)
+    model = cda.create_model("residual", n_mels=rows, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    model.cuda().eval()
+    pipe = cda.CoughPipeline(pre, model)
+    w = synth_batch(1300, 45, peak_normalize=False) * 0.6
+    logits = pipe(w.cuda(), normalize=True)
+    feats = pre.featurize_batch(w.cuda(), normalize=True)
+    assert feats.shape == (45, rows, 101) and torch.equal(logits, model(feats[:, None]))
+    g = dict(sample_rate=16000, n_mels=64, n_fft=512, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13)
+    g.update(geom)
+    ref = ores.forward(ofeat.extract_features_batch(w, normalize_first=True, **flags, **ofeat.geometry_kwargs(**g)).unsqueeze(1), sd)
+    err = (logits.cpu() - ref).abs().max().item()
+    print(f"{kw}: fused pipeline logits max abs err {err:.2e}")
+    assert err < LOGIT_TOL and torch.equal(logits.cpu().argmax(1), ref.argmax(1))
