@@ -617,39 +617,39 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         K1_STAMP(5);   // DCT + mean + std done
         for (int i = tid; i < nmf; i += THREADS) mf[i] = (mf[i] - mean) * rdenom;
     } else {
-    const int c0 = chalf * 7, nc = chalf ? 6 : 7;
-    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (tt < NFRAMES) {
-        const float* drow = &tb->dct_t[c0][0];
-        // seven coefficients for both halves (the second half's seventh is the table's zero row): no branch in the
-        // loop, so the wave-uniform coefficients arrive as s_load_dwordx8 blocks -- a conditional seventh coefficient
-        // made every one of its 64 products wait out a scalar load of its own
+        const int c0 = chalf * 7, nc = chalf ? 6 : 7;
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tt < NFRAMES) {
+            const float* drow = &tb->dct_t[c0][0];
+            // seven coefficients for both halves (the second half's seventh is the table's zero row): no branch in the
+            // loop, so the wave-uniform coefficients arrive as s_load_dwordx8 blocks -- a conditional seventh coefficient
+            // made every one of its 64 products wait out a scalar load of its own
 #pragma unroll 8
-        for (int m = 0; m < NMEL; ++m) {
-            const float v = melbuf[m * NFRAMES + tt];
+            for (int m = 0; m < NMEL; ++m) {
+                const float v = melbuf[m * NFRAMES + tt];
 #pragma unroll
-            for (int cc = 0; cc < 7; ++cc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
+                for (int cc = 0; cc < 7; ++cc) acc[cc] = fmaf(drow[cc * NMEL + m], v, acc[cc]);
+            }
         }
-    }
-    K1_MARK("PHASE P2 mean / std / z-score");
-    float lsum = 0.f;
+        K1_MARK("PHASE P2 mean / std / z-score");
+        float lsum = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 7; ++cc) lsum += (tt < NFRAMES && cc < nc) ? acc[cc] : 0.f;
-    const float mean = block_sum(lsum, red, tid) / float(NMF);
-    K1_STAMP(5);   // DCT done
-    float lsq = 0.f;
+        for (int cc = 0; cc < 7; ++cc) lsum += (tt < NFRAMES && cc < nc) ? acc[cc] : 0.f;
+        const float mean = block_sum(lsum, red, tid) / float(NMF);
+        K1_STAMP(5);   // DCT done
+        float lsq = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 7; ++cc) {
-        const float d = acc[cc] - mean;
-        lsq += (tt < NFRAMES && cc < nc) ? d * d : 0.f;
-    }
-    const float sd = sqrtf(block_sum(lsq, red, tid) / float(NMF - 1));   // torch.std: unbiased
-    const float rdenom = 1.0f / (sd + 1e-8f);                              // (x - mean) / (std + 1e-8), :428
-    if (tt < NFRAMES) {
+        for (int cc = 0; cc < 7; ++cc) {
+            const float d = acc[cc] - mean;
+            lsq += (tt < NFRAMES && cc < nc) ? d * d : 0.f;
+        }
+        const float sd = sqrtf(block_sum(lsq, red, tid) / float(NMF - 1));   // torch.std: unbiased
+        const float rdenom = 1.0f / (sd + 1e-8f);                              // (x - mean) / (std + 1e-8), :428
+        if (tt < NFRAMES) {
 #pragma unroll
-        for (int cc = 0; cc < 7; ++cc)
-            if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
-    }
+            for (int cc = 0; cc < 7; ++cc)
+                if (cc < nc) mf[(c0 + cc) * NFRAMES + tt] = (acc[cc] - mean) * rdenom;
+        }
     }
     __syncthreads();
     K1_MARK("PHASE P2 feature image (stem) + MFCC / delta rows");
