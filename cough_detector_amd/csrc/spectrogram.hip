@@ -213,7 +213,10 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             // (IMG_PIECES - 2) / THREADS3 of them.  A build without the stores has nothing behind the DMA: vmcnt(0).
             static_assert((IMG_PIECES - 2) / THREADS3 >= 7, "round 0 waits with vmcnt(7): every wave must issue >= 7 flush stores after its DMA");
 #ifndef COUGH_STFT_NO_STORE
-            if (rd == 0 && !CENT && VMW > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+            // CENT: the one vector-memory operation behind this group's DMA is the previous round's centroid store (every group
+            // holds at least one valid frame, so that store always issues): waiting for it as well would expose its latency
+            if constexpr (CENT) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (rd == 0 && VMW > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

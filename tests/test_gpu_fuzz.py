@@ -227,3 +227,36 @@ def test_tuned_kernel_every_flag_combination_on_hard_inputs():
         assert err < 3 * FEAT_TOL, (kw, d)
     print(f"32 flag combinations x 8 hard inputs at the shipped geometry: worst error on the 6 well-conditioned inputs {worst:.2e} "
           f"(the 2 ill-conditioned ones: {worst_ill:.2e})")
+
+
+def test_fullband_featuriser_random_filterbanks_and_flags():
+    """40 seeded random filterbanks at the shipped STFT geometry -- n_mels (even, 2..128), n_mfcc (1..20), f_min / f_max up to the
+    Nyquist bin, every flag the full-band one-launch kernel takes (PCEN at 64 bands) -- against the CPU oracle; every case must
+    land on the one-launch kernel (`tuned` or `tuned_fullband`), none on the generic chain."""
+    rng = np.random.default_rng(505)
+    w = synth_batch(2100, 10, peak_normalize=False)
+    paths = {"tuned": 0, "tuned_fullband": 0}
+    for case in range(40):
+        n_mels = int(rng.choice([2, 8, 20, 26, 40, 64, 64, 64, 80, 96, 128]))
+        n_mfcc = int(rng.integers(1, min(n_mels, 20) + 1))
+        f_min = float(rng.choice([0.0, 20.0, 100.0, 300.0, 1000.0]))
+        f_max = float(rng.choice([2000.0, 3500.0, 4000.0, 5000.0, 7000.0, 8000.0]))
+        flags = dict(use_pre_emphasis=bool(rng.integers(2)), use_delta_delta=bool(rng.integers(2)),
+                     use_pcen=bool(rng.integers(2)) and n_mels == 64, use_mfcc=bool(rng.integers(4) > 0),
+                     use_spectral_contrast=bool(rng.integers(4) == 0), n_contrast_bands=int(rng.integers(1, 5)))
+        g = dict(sample_rate=16000, n_mels=n_mels, n_fft=512, hop_length=160, win_length=400, f_min=f_min, f_max=f_max, n_mfcc=n_mfcc)
+        pre = cda.AudioPreprocessor(device="cuda", **g, **flags)
+        assert pre.kernel_path() in paths, (case, g, flags, pre.kernel_path())
+        paths[pre.kernel_path()] += 1
+        normalize = bool(rng.integers(2))
+        f = pre.featurize_batch(w.cuda(), normalize=normalize).cpu()
+        ref = ofeat.extract_features_batch(w, normalize_first=normalize, **ofeat.geometry_kwargs(**g), **flags)
+        assert f.shape == ref.shape, (case, g, flags)
+        nbase = n_mels + ((2 * n_mfcc + (n_mfcc if flags["use_delta_delta"] else 0)) if flags["use_mfcc"] else 0)
+        mel = (f[:, :n_mels] - ref[:, :n_mels]).abs().max().item()
+        zr = f[:, n_mels:nbase], ref[:, n_mels:nbase]
+        rel = ((zr[0] - zr[1]).abs() / zr[1].abs().clamp(min=1.0)).max().item() if nbase > n_mels else 0.0
+        cerr = (f[:, nbase:] - ref[:, nbase:]).abs().max().item() if flags["use_spectral_contrast"] else 0.0
+        assert mel < 1e-4 and rel < 1e-4 and cerr < 2e-4, (case, g, flags, normalize, mel, rel, cerr)
+    print(f"full-band fuzz: {paths}")
+    assert paths["tuned_fullband"] >= 30

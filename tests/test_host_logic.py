@@ -53,6 +53,11 @@ def test_argument_errors_need_no_gpu():
     assert b"NULL" in lib.cough_amd_last_error()
     with pytest.raises(ValueError):
         _lib.check(lib.cough_resnet_create(None, None, 0), "x")
+    # the ABI v5 entry points refuse NULL / negative arguments before anything touches a GPU
+    assert lib.cough_featurize_any(None, None, 16000, 12000, None, 1, 0, None, 0, None) == _lib.EINVAL
+    assert lib.cough_spectrogram_any(None, None, 16000, 12000, None, 1, 0, None) == _lib.EINVAL
+    assert lib.cough_featurizer_num_frames_for(None, 16000) == -1 and lib.cough_featurizer_path(None) == -1
+    assert lib.cough_featurizer_workspace_bytes_for(None, 16000, 4) == 0
 
 
 def test_product_tables_equal_oracle_tables():
