@@ -170,7 +170,10 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps) {
 // delta-delta; src/preprocessing.py:43-49, :471-474).  Its hi + lo images (2 x 23 KB) do not fit beside the MFCC / delta
 // buffers in a workgroup's 45.5 KB, so the stem runs in two halves of 13 pooled rows out of a 58-row image each -- three
 // workgroups per CU as for the shipped layout.
-template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false>
+// PCS: the fused stem's mel rows are the PCEN values (use_pcen with a fused stem) -- a template parameter because the values
+// wait in 26 registers from the PCEN branch to the image build, which costs the shipped instantiation 1.3 % when it is a run-time
+// choice (same-box A/B, profiles/r05_bench_flags.txt).
+template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false, bool PCS = false>
 __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
@@ -515,6 +518,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const float floor_db = fmaxf(raw_max - shift, -100.0f) - 80.0f;
     K1_STAMP(3);   // all waves finished P1
     bool wr_mel = wr;
+    // STEM == 2 with PCEN: the thread's 26 normalised PCEN values stay in registers until the feature image is built (the dB
+    // buffer is still needed for the MFCC branch in between)
+    [[maybe_unused]] float pcv[PCS ? 26 : 1];
     K1_MARK("SKIP PCEN branch (off in the shipped configuration)");
     if (pcen) {
         // PCEN branch of extract_mel_spectrogram (preprocessing.py:305-340, :400-404): mel rows =
@@ -547,6 +553,10 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 #pragma unroll
             for (int k = 0; k < 26; ++k)
                 if (t0 + k < t1) o[m * NFRAMES + t0 + k] = (pv[k] - mn) * rng;
+        }
+        if constexpr (PCS) {
+#pragma unroll
+            for (int k = 0; k < 26; ++k) pcv[k] = (pv[k] - mn) * rng;
         }
         wr_mel = false;   // the log-mel pass below only prepares the floored dB for the MFCC branch
     }
@@ -713,7 +723,16 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             __syncthreads();
         };
         zero_image();
-        {
+        if constexpr (PCS) {   // mel rows = the PCEN values this thread formed for (band tid / 4, quarter tid % 4 of the frames)
+            const int m = tid >> 2, t0 = (tid & 3) * 26;
+#pragma unroll
+            for (int k = 0; k < 26; ++k) {
+                if (t0 + k < NFRAMES) {
+                    if (m + 3 < TL_ROWS - 1) tput((m + 3) * ST_PITCH + t0 + k + 3, pcv[k]);
+                    if (m >= TL_KEEP0) stash[(m - TL_KEEP0) * NFRAMES + t0 + k] = pcv[k];
+                }
+            }
+        } else {
             {
 #pragma unroll
                 for (int it = 0; it < NDV; ++it) {
@@ -825,14 +844,21 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         for (int i = tid; i < NIMG * ST_ROWS * ST_PITCH / 8; i += THREADS) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
         for (int i = (NIMG * ST_ROWS * ST_PITCH / 8) * 8 + tid; i < NIMG * ST_ROWS * ST_PITCH; i += THREADS) img[i] = 0;
         __syncthreads();
+        if constexpr (PCS) {   // mel rows = the PCEN values this thread formed for (band tid / 4, quarter tid % 4 of the frames)
+            const int m = tid >> 2, t0 = (tid & 3) * 26;
 #pragma unroll
-        for (int it = 0; it < (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS; ++it) {
-            const int e = 2 * (tid + it * THREADS);
-            if (e < NMEL * NFRAMES) {
-                const int m0 = e / NFRAMES, t0 = e - m0 * NFRAMES;
-                const int m1 = t0 + 1 < NFRAMES ? m0 : m0 + 1, t1 = t0 + 1 < NFRAMES ? t0 + 1 : 0;
-                put((m0 + 3) * ST_PITCH + t0 + 3, fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f));
-                put((m1 + 3) * ST_PITCH + t1 + 3, fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f));
+            for (int k = 0; k < 26; ++k)
+                if (t0 + k < NFRAMES) put((m + 3) * ST_PITCH + t0 + k + 3, pcv[k]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < (NMEL * NFRAMES / 2 + THREADS - 1) / THREADS; ++it) {
+                const int e = 2 * (tid + it * THREADS);
+                if (e < NMEL * NFRAMES) {
+                    const int m0 = e / NFRAMES, t0 = e - m0 * NFRAMES;
+                    const int m1 = t0 + 1 < NFRAMES ? m0 : m0 + 1, t1 = t0 + 1 < NFRAMES ? t0 + 1 : 0;
+                    put((m0 + 3) * ST_PITCH + t0 + 3, fminf(fmaxf((dv[it].x + 80.0f) * 0.0125f, 0.f), 1.f));
+                    put((m1 + 3) * ST_PITCH + t1 + 3, fminf(fmaxf((dv[it].y + 80.0f) * 0.0125f, 0.f), 1.f));
+                }
             }
         }
     }
@@ -1126,7 +1152,11 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                              reinterpret_cast<const void*>(featurize_kernel<false, 2, true, false>),
                              reinterpret_cast<const void*>(featurize_kernel<false, 2, true, true>),
                              reinterpret_cast<const void*>(featurize_kernel<true, 2, true, false>),
-                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true>)};
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true, false, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<false, 2, true, true, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, false, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true, true>)};
         for (const void* fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
@@ -1176,14 +1206,12 @@ int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
 bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->kind != 0 && (n_samples <= 0 || n_samples == NS); }
 bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
-    // a one-launch kernel writing the whole image (no contrast rows), 64 mel + 13 MFCC rows, log-mel (the PCEN rows are formed in
-    // another thread mapping than the image is built in)
-    if (f->kind == 0 || f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->cfg.use_pcen || f->nfeat != f->nbase)
-        return false;
+    // a one-launch kernel writing the whole image (no contrast rows), 64 mel + 13 MFCC rows
+    if (f->kind == 0 || f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->nfeat != f->nbase) return false;
     // split-bf16 stem: the 90-row layout, or the 103-row layout of the delta-delta flag (two halves); shipped or full-band
-    // filterbank, with or without pre-emphasis.  The approximate single-bf16 stem exists for the shipped 90-row set only.
+    // filterbank, with or without pre-emphasis / PCEN.  The approximate single-bf16 stem exists for the shipped 90-row set only.
     if (x3) return f->nfeat == ST_H || (f->nfeat == ST_H + NMFCC && f->cfg.use_delta_delta);
-    return f->nfeat == ST_H && f->kind == 1 && !f->cfg.use_pre_emphasis;
+    return f->nfeat == ST_H && f->kind == 1 && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
     if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
@@ -1229,16 +1257,16 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     };
     if (stem && stem->x3) {   // split-bf16 stem fused (90-row image, or the 103-row image of the delta-delta flag in two halves)
         const bool tall = f->cfg.use_delta_delta != 0;
-        const int sel = (pe ? 4 : 0) | (full ? 2 : 0) | (tall ? 1 : 0);
+        const int sel = (f->cfg.use_pcen ? 8 : 0) | (pe ? 4 : 0) | (full ? 2 : 0) | (tall ? 1 : 0);
         switch (sel) {
-            case 0: go(featurize_kernel<false, 2, false, false>, *stem, 0); break;
-            case 1: go(featurize_kernel<false, 2, false, true>, *stem, 0); break;
-            case 2: go(featurize_kernel<false, 2, true, false>, *stem, 0); break;
-            case 3: go(featurize_kernel<false, 2, true, true>, *stem, 0); break;
-            case 4: go(featurize_kernel<true, 2, false, false>, *stem, 0); break;
-            case 5: go(featurize_kernel<true, 2, false, true>, *stem, 0); break;
-            case 6: go(featurize_kernel<true, 2, true, false>, *stem, 0); break;
-            default: go(featurize_kernel<true, 2, true, true>, *stem, 0); break;
+#define K1_CASE(N, PE, FU, TA, PC) case N: go(featurize_kernel<PE, 2, FU, TA, PC>, *stem, PC ? 1 : 0); break;
+            K1_CASE(0, false, false, false, false) K1_CASE(1, false, false, true, false) K1_CASE(2, false, true, false, false)
+            K1_CASE(3, false, true, true, false) K1_CASE(4, true, false, false, false) K1_CASE(5, true, false, true, false)
+            K1_CASE(6, true, true, false, false) K1_CASE(7, true, true, true, false) K1_CASE(8, false, false, false, true)
+            K1_CASE(9, false, false, true, true) K1_CASE(10, false, true, false, true) K1_CASE(11, false, true, true, true)
+            K1_CASE(12, true, false, false, true) K1_CASE(13, true, false, true, true) K1_CASE(14, true, true, false, true)
+            default: go(featurize_kernel<true, 2, true, true, true>, *stem, 1); break;
+#undef K1_CASE
         }
     } else if (stem) {        // approximate single-bf16 stem: shipped filterbank, no pre-emphasis (featurizer_stem_fusable)
         go(featurize_kernel<false, 1>, *stem, 0);

@@ -163,10 +163,13 @@ def test_delta_delta_pipeline_keeps_the_stem_fused_in_two_halves(resnet_heights_
 
 @pytest.mark.parametrize("kw", [dict(use_pre_emphasis=True), dict(use_pre_emphasis=True, use_delta_delta=True),
                                 dict(f_max=8000.0, use_delta_delta=True), dict(f_max=8000.0, use_pre_emphasis=True),
-                                dict(f_max=8000.0, use_pre_emphasis=True, use_delta_delta=True)],
-                         ids=["preemph", "preemph_dd", "fullband_dd", "fullband_preemph", "fullband_preemph_dd"])
+                                dict(f_max=8000.0, use_pre_emphasis=True, use_delta_delta=True),
+                                dict(use_pcen=True), dict(use_pcen=True, use_pre_emphasis=True, use_delta_delta=True),
+                                dict(f_max=8000.0, use_pcen=True, use_delta_delta=True)],
+                         ids=["preemph", "preemph_dd", "fullband_dd", "fullband_preemph", "fullband_preemph_dd", "pcen",
+                              "pcen_preemph_dd", "fullband_pcen_dd"])
 def test_every_fused_stem_instantiation_equals_featurise_then_classify(resnet_golden, resnet_heights_golden, kw):
-    """The split-bf16 stem stays inside the featurise kernel for pre-emphasis, for any filterbank at the shipped STFT geometry and
+    """The split-bf16 stem stays inside the featurise kernel for pre-emphasis, PCEN mel rows, any filterbank at the shipped STFT geometry and
     for the 103-row delta-delta image, in every combination (featurize_kernel<PRE_EMPH, 2, FULL, TALL>): bit-identical to the
     two-step path, within 1e-3 of the CPU oracle."""
     flags = {**SHIPPED, **{k: v for k, v in kw.items() if k.startswith("use_")}}
