@@ -1,31 +1,31 @@
-// K1 -- fused featuriser for gfx950: waveform -> log-mel(64) + MFCC(13) + delta(13) [+ delta-delta].
+// K1 -- fused featuriser for gfx950: waveform -> log-mel / PCEN rows + MFCC + delta [+ delta-delta] [+ the classifier's stem].
 //
 // Replaces AudioPreprocessor.normalize / extract_features
 // (/root/reference/src/preprocessing.py:199-212, :432-489) and the torchaudio transforms it calls
-// (T.MelSpectrogram :94-106, T.AmplitudeToDB :109-112, T.MFCC :116-127).  The reference runs the
-// STFT->mel->dB chain twice per clip (:398 and :425); here one pass feeds both branches.
+// (T.MelSpectrogram :94-106, T.AmplitudeToDB :109-112, T.MFCC :116-127) at the shipped STFT geometry (16 kHz, n_fft 512,
+// hop 160, window 400, 1 s = 101 frames) for ANY filterbank.  The reference runs the STFT->mel->dB chain twice per clip (:398
+// and :425); here one pass feeds both branches.
 //
-// One 4-wave workgroup per clip, 43 KB of LDS, so three clips are in flight per CU and their
-// phases overlap (one loads from HBM while another runs FFTs and a third stores).  All three
-// per-clip reductions (peak for normalize, dB max for top_db, MFCC mean/std) are block reductions,
-// so batches keep the reference's per-clip semantics.
+// One 4-wave workgroup per clip, 45.5 KB of LDS, so three clips are in flight per CU and their phases overlap (one loads from
+// HBM while another runs FFTs and a third stores).  All three per-clip reductions (peak for normalize, dB max for top_db,
+// MFCC mean / std) are block reductions, so batches keep the reference's per-clip semantics.
 //
-//   P0  none.  Peak normalisation (x / max|x|) commutes with everything up to the dB stage:
-//       power scales by 1/peak^2, so dB(x/peak) = max(dB(x) - 20*log10(peak), -100) (the -100 is the
-//       reference's amin = 1e-10 clamp).  The peak is collected from the samples the frames load anyway
-//       (every sample lies under some frame's live taps), so the clip is read from HBM exactly once.
-//   P1  per frame (16 lanes each, 4 frames per wave pass): samples straight from global/L2
-//       (8-byte loads, each sample is touched 2.5x but fetched from HBM once; the 4 edge frames take a
-//       reflected-index path = torch.stft center/reflect), window taps from registers, packed as 256
-//       complex points; 256-pt FFT = radix-16 (registers) -> twiddle (register table) -> LDS transpose
-//       (re then im through the same 17-float-pitch scratch) -> radix-16; real-input split for bins
-//       0..127 (lanes i and 16-i trade their upper halves by ds_bpermute); |X|^2 -> LDS; sparse mel
-//       (lane = band, <= 8 taps + start bin in registers); 10*log10 -> LDS
-//   P2  block max -> top_db floor -> mel rows out; 13x64 DCT with wave-uniform (scalar) coefficients;
-//       mean / unbiased std; z-score, deltas out
+//   P0  none.  Peak normalisation (x / max|x|) commutes with everything up to the dB stage: power scales by 1/peak^2, so
+//       dB(x/peak) = max(dB(x) - 20*log10(peak), -100) (the -100 is the reference's amin = 1e-10 clamp).  The peak is collected
+//       from the samples the frames load anyway, so the clip is read from HBM exactly once.  A clip whose peak lies outside
+//       2^-50 .. 2^50 is transformed a second time with scaled window taps (a cold copy of P1); a NaN / Inf sample makes the
+//       whole image NaN, as in the reference.
+//   P1  per frame (16 lanes each, 4 frames per wave pass): samples straight from global one group ahead (8-byte loads; the 4
+//       edge frames take a reflected-index path = torch.stft center / reflect), window taps from registers, packed as 256
+//       complex points; 256-pt FFT = radix-16 (registers) -> twiddle (LDS table) -> 16x16 transpose through LDS -> radix-16;
+//       real-input split; |X|^2 -> LDS; mel (lane = band); 10*log10 on the hardware log2 -> LDS
+//   P2  block max -> top_db floor -> mel rows out (or PCEN); DCT with wave-uniform (scalar) coefficients; mean / unbiased std;
+//       z-score, deltas out; STEM: bf16 hi / lo feature images in LDS -> conv7x7 + BN + ReLU + maxpool on the matrix cores
 //
-// Only bins 4..127 feed the shipped 100 Hz-4 kHz filterbank, so the upper half
-// of the spectrum is never formed.
+// Template parameters (21 instantiations): PRE_EMPH (pre-emphasis while loading), STEM (0 none / 1 bf16 / 2 split-bf16 stem
+// fused), FULL (full-band: all 257 bins, CSR filterbank in LDS, run-time n_mels / n_mfcc; otherwise the shipped sparse bank:
+// <= 8 register taps per band below bin 128, only bins 0..127 formed), TALL (103-row delta-delta image, stem in two halves),
+// PCS (PCEN values feed the stem).
 #include <cmath>
 #include <cstddef>
 #include <cstring>

@@ -51,10 +51,12 @@ const char* cough_amd_last_error(void);  /* thread-local, never NULL */
  * 16 <= n_fft <= 2048 (even or odd): any sample_rate, hop_length >= 1, win_length <= n_fft, n_mels <= 256,
  * n_mfcc <= n_mels, any filterbank (f_min / f_max), any segment longer than n_fft / 2 samples (RealtimePreprocessor's
  * window_duration, :559-580; the engine's re-construction from a checkpoint config,
- * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry,
- * which (with a filterbank of <= 8 taps per band below bin 128, i.e. f_max <= sample_rate / 4) runs on
- * the tuned one-launch kernel; every other geometry runs on a chain of small kernels and NEEDS A
- * WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws).  n_fft = 512 (the reference's
+ * /root/reference/src/inference.py:89-108).  The values in the comments below are the shipped geometry.
+ * At the shipped STFT geometry (16 kHz, n_fft 512, hop 160, window 400, 1 s) ANY filterbank runs on the one-launch
+ * kernel (cough_featurizer_path: the shipped sparse bank with its taps in registers, every other bank -- f_max up to the
+ * Nyquist bin, 2..128 bands, <= 20 MFCCs -- on the full-band instantiations); every other geometry runs on a chain of
+ * small kernels and NEEDS A WORKSPACE (cough_featurizer_workspace_bytes > 0: use cough_featurize_ws), as do the
+ * spectral-contrast rows and waveforms of another length (cough_featurize_any).  n_fft = 512 (the reference's
  * default) uses the register radix-16 x radix-16 FFT, the other powers of two >= 64 a radix-4 Stockham kernel, every
  * other n_fft (400 = torchaudio's own default, odd sizes) a direct DFT on the f32 matrix cores -- exact, O(n_fft^2), 2-3x slower; the frame
  * count is torch.stft's, (N - n_fft % 2) / hop_length + 1; n_fft outside 16 .. 2048 returns COUGH_EUNSUPPORTED.
