@@ -221,7 +221,7 @@ def stft_stage(pre, batches, launches: int = 210, warm: int = 60) -> dict:
                 break
         except (OSError, KeyError, ValueError):
             pass
-    return {"kernel": "stft3_kernel (waveform -> 257x101 power spectrogram; persistent, one 13-wave workgroup per CU)",
+    return {"kernel": "stft3_kernel (waveform -> 257x101 power spectrogram; persistent, one 12-wave workgroup per CU)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),
             "algorithmic_bytes_per_launch": b * BYTES_PER_CLIP_STFT, "traffic": traffic, "traffic_source": src,

@@ -8,7 +8,7 @@
 // The fused featuriser (featurize.hip) never materialises the spectrogram; this file is the same FFT with all 257 bins
 // formed and stored.  Algorithmic bytes per clip: 64 000 read + 257*101*4 = 103 828 written.
 //
-// The kernel that runs is stft3_kernel (below): one persistent 13-wave workgroup per CU owns a clip's whole spectrogram,
+// The kernel that runs is stft3_kernel (below): one persistent 12-wave workgroup per CU owns a clip's whole spectrogram,
 // stages it in LDS as the linear image it is in memory and writes it with aligned 16-byte stores; samples arrive by
 // LDS-DMA.  0.169 ms for 4096 clips = 51 % of 8 TB/s, PMC traffic 1.001x (profiles/r03_stft_experiments.txt).
 //
@@ -46,15 +46,17 @@ __device__ unsigned long long* g_stft_stamp_buf = nullptr;
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-// stft3_kernel: one PERSISTENT 13-wave workgroup per CU, one clip at a time, whole spectrogram staged in LDS.
+// stft3_kernel: one PERSISTENT 12-wave workgroup per CU, one clip at a time, whole spectrogram staged in LDS.
 //
 // Why: the (bin, time) output is time-minor with 404-byte rows, so a workgroup that owns a range of frames writes
 // 60-110-byte row fragments at 4-byte alignment and relies on sibling workgroups' fragments meeting in L2 (stft_kernel
 // above).  Here a workgroup owns the clip's WHOLE 257 x 101 spectrogram -- one contiguous 103 828-byte range of the
 // output -- builds it in LDS as the linear image it is in memory, and writes it with 16-byte-per-lane stores at
 // 16-byte-aligned addresses: every 128-byte line leaves the CU whole, once, in one burst.
-//   * 26 four-frame groups = 13 waves x 2 rounds exactly; the clip's image (103.8 KB) + 13 transpose scratches of
-//     4 160 B + twiddle and window tables = 162 KB of the CU's 160 KiB (163 840 B).
+//   * 26 four-frame groups over 12 waves: two each, waves 0 and 1 (on different SIMDs) a third -- r05: three waves per SIMD and
+//     the worst SIMD at 7 group-rounds measured 1.5 % faster than 13 waves (SIMD 0 hosting four, 8 group-rounds; r03 / r04),
+//     same-box A/B in profiles/r05_stft_waves_ab.txt; COUGH_STFT_WAVES selects.  The clip's image (103.8 KB) + 12 transpose scratches of
+//     4 160 B + twiddle and window tables = 157 984 B of the CU's 160 KiB (163 840 B).
 //   * A wave's 992 samples per group come straight from HBM into its transpose scratch by `global_load_lds_dwordx4`
 //     (no data VGPRs; reflected edges: dword DMAs with per-lane reflected source addresses), and the NEXT group's
 //     samples (the next clip's, in round 1) are requested as soon as the second transpose has been read back, so
@@ -64,17 +66,24 @@ __device__ unsigned long long* g_stft_stamp_buf = nullptr;
 //     half-wave, every address is a per-lane base + an immediate, and it takes 1040 floats instead of 4 x 272.
 //   * Raw `s_barrier`s behind `lgkmcnt(0)` (a `__syncthreads()` would drain the DMA); the samples are awaited with a
 //     counted `vmcnt` that leaves the flush stores issued after the DMA in flight.
-constexpr int W3 = 13, THREADS3 = W3 * 64;                              // 832 threads
+#ifndef COUGH_STFT_WAVES
+#define COUGH_STFT_WAVES 12
+#endif
+#ifndef COUGH_STFT_WIN_REGS
+#define COUGH_STFT_WIN_REGS 0
+#endif
+constexpr int W3 = COUGH_STFT_WAVES, THREADS3 = W3 * 64;                // 768 threads
+constexpr int ROUNDS3 = (NGROUP + W3 - 1) / W3;                         // four-frame groups of a clip per wave, at most
 constexpr int GSPAN = (FPW - 1) * HOP + NFFT;                           // 992 samples feed one four-frame group
 constexpr int X3ROW = FPW * 16 + 1, X3WAVE = 16 * X3ROW;                // transpose scratch: [16 rows][4 frames x 16 + 1 pad]
 constexpr int IMG = NFREQ * NFRAMES;                                    // 25 957 floats
 constexpr int IMG_PIECES = (IMG + 3 + 3) / 4;                           // 16-byte pieces incl. up to 3 floats of lead-in
 constexpr size_t LDS3_IMG = size_t(IMG_PIECES) * 16;                    // 103 840
-constexpr size_t LDS3_XCH = size_t(W3) * X3WAVE * 4;                    // 54 080
+constexpr size_t LDS3_XCH = size_t(W3) * X3WAVE * 4;                    // 49 920
 constexpr size_t LDS3_WIN = size_t(NFFT) * 4;                           // 2 048
-constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN;  // 162 144
+constexpr size_t LDS3_TOTAL = LDS3_IMG + LDS3_XCH + LDS_TW + LDS3_WIN;  // 157 984
 static_assert(LDS3_TOTAL <= 160 * 1024, "one workgroup owns the CU's LDS");
-static_assert(W3 * 2 == NGROUP, "13 waves x 2 rounds = 26 groups");
+static_assert(W3 * ROUNDS3 >= NGROUP && W3 <= 16, "every group of a clip has a wave");
 static_assert(GSPAN <= X3WAVE && GSPAN % 4 == 0, "a group's samples land in the wave's transpose scratch");
 static_assert(LDS3_IMG % 16 == 0 && LDS3_XCH % 16 == 0 && LDS_TW % 16 == 0, "16-byte aligned regions");
 
@@ -191,6 +200,13 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
     int iter_no = 0;
 #endif
 
+    // window taps from LDS; COUGH_STFT_WIN_REGS keeps them in registers (three waves per SIMD leave 168 VGPRs): measured no faster
+    constexpr bool WIN_REGS = COUGH_STFT_WIN_REGS != 0;
+    [[maybe_unused]] float2 wreg[16];
+    if constexpr (WIN_REGS) {
+#pragma unroll
+        for (int n1 = N0; n1 < N1; ++n1) wreg[n1] = *reinterpret_cast<const float2*>(winl + 2 * j + 32 * n1);
+    }
     bool first = true;
     while (true) {
         STFT3_STAMP(0);
@@ -204,8 +220,9 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             if (peaks != nullptr) cs = extreme_peak_scale(peaks[clip]);
         }
 #pragma unroll 1
-        for (int rd = 0; rd < 2; ++rd) {
+        for (int rd = 0; rd < ROUNDS3; ++rd) {
             const int g = wave + W3 * rd;
+            if (g >= NGROUP) break;   // wave-uniform (12 waves: waves 0 and 1 take a third group)
             // this group's samples are in the scratch.  Round 0: everything but the flush stores issued after the DMA
             // (at least 7 per wave) has completed; round 1: nothing was issued after its DMA
             // The 7: every wave issues >= 7 flush stores behind the DMA -- the flush below hands thread t pieces t,
@@ -228,11 +245,11 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
                 a[15] = make_float2(0.f, 0.f);
             }
             const float* sp = myw + HOP * fsub + 2 * j;
-            const float* wp = winl + 2 * j;
+            [[maybe_unused]] const float* wp = winl + 2 * j;
 #pragma unroll
             for (int n1 = N0; n1 < N1; ++n1) {
                 const float2 r = *reinterpret_cast<const float2*>(sp + 32 * n1);
-                const float2 w = *reinterpret_cast<const float2*>(wp + 32 * n1);
+                const float2 w = WIN_REGS ? wreg[n1] : *reinterpret_cast<const float2*>(wp + 32 * n1);
                 if constexpr (PEAK) a[n1] = make_float2((r.x * cs) * w.x, (r.y * cs) * w.y);
                 else a[n1] = make_float2(r.x * w.x, r.y * w.y);
             }
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(THREADS3) void stft3_kernel(const float* __restrict
             for (int n2 = 0; n2 < 16; ++n2) z[n2].y = xr[n2];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is dead: every read of it has returned
             if (rd == 0) STFT3_STAMP(2);
-            if (rd == 0) dma_group(wav + clip * wav_stride, wave + W3);
+            if (g + W3 < NGROUP) dma_group(wav + clip * wav_stride, g + W3);
             else if (clip_n < n_clips) dma_group(wav + clip_n * wav_stride, wave);
             if (rd == 0) STFT3_STAMP(3);
             dft16(z);   // z[k2] = Z[j + 16*k2]
