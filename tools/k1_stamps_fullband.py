@@ -34,8 +34,6 @@ for name, kw in (("shipped", {}), ("f_max 8000 / 64 mel", dict(f_max=8000.0)), (
     st = stamps.view(B, 8).cpu().double()
     d = st[:, 1:7] - st[:, 0:6]
     total = st[:, 6] - st[:, 0]
-    span = st[:, 6].max() - st[:, 0].min()
-    print(f"{name} [{pre.kernel_path()}]: median workgroup lifetime {total.median():.0f} ticks, grid span {span:.0f} ticks "
-          f"(resident workgroups ~ {B * total.mean() / span / 256:.2f} per CU)")
+    print(f"{name} [{pre.kernel_path()}]: median workgroup lifetime {total.median():.0f} cycles")
     for i, n in enumerate(NAMES):
         print(f"  {n:36s} median {d[:, i].median():9.0f}  share {100 * d[:, i].median() / total.median():5.1f}%")
