@@ -71,3 +71,20 @@ def test_roofline_traffic_is_collected_live_with_rocprofv3(monkeypatch, capsys):
     assert rs["traffic_source"].startswith("live: rocprofv3 --pmc") and 0.97 < rs["traffic"] / (512 * 167828) < 1.08
     busy = d["roofline_classifier"]["mfma_pipe_busy"]
     assert 0.05 < busy["block0"] < 1.0 and 0.05 < busy["block1"] < 1.0
+
+
+def test_streaming_bench_prints_one_aggregated_line(monkeypatch, capsys):
+    """bench_streaming.py (configs[4]): ONE JSON line for the job -- p50 as `value`, global percentiles, aggregate windows/s,
+    one record per rank -- in-process at 8 streams x 4 s (the N > 1 aggregation is covered by gloo tests on CPU)."""
+    import bench_streaming
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("COUGH_BENCH_FORCE_DIST", raising=False)
+    assert bench_streaming.main(["--streams", "8", "--seconds", "4"]) == 0
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["unit"] == "ms" and d["higher_is_better"] is False and d["n_gpus"] == d["rccl_world"] == 1
+    assert d["value"] == d["latency_ms_p50"] and 0 < d["latency_ms_p50"] <= d["latency_ms_p99"] <= d["latency_ms_max"] < 50
+    assert d["config"]["streams"] == 8 and len(d["ranks"]) == 1 and d["ranks"][0]["streams"] == 8
+    assert d["windows"] == 8 * 13 == d["ranks"][0]["windows"]                     # (4 s - 1 s) / 0.25 s + 1 windows per stream
+    assert d["sustained_windows_per_s"] > d["real_time_need_windows_per_s"] == 32.0
