@@ -48,11 +48,10 @@ def test_pipeline_full_batch_against_oracle(resnet_golden):
     err = (logits[sample].cpu() - ref).abs().max().item()
     print(f"pipeline bf16x3 B=4096 sample: logits max abs err {err:.2e}")
     assert err < LOGIT_TOL
-    keep = (ref[:, 1] - ref[:, 0]).abs() > 2 * LOGIT_TOL
     flips = int((logits[sample].cpu().argmax(1) != ref.argmax(1)).sum())
-    print(f"pipeline bf16x3 B=4096: {int((~keep).sum())} of {len(sample)} sampled clips fall under the argmax mask "
-          f"(|margin| <= {2 * LOGIT_TOL}); argmax differs on {flips}")
-    assert torch.equal(logits[sample].cpu().argmax(1)[keep], ref.argmax(1)[keep]) and keep.float().mean() > 0.98
+    print(f"pipeline bf16x3 B=4096: argmax differs on {flips} of {len(sample)} sampled clips (no mask; smallest reference margin "
+          f"{(ref[:, 1] - ref[:, 0]).abs().min().item():.2e})")
+    assert flips == 0                                                     # argmax exact on EVERY sampled clip, no margin mask
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record(); ev[1].record()
     pipe(w.cuda(), events=ev)
