@@ -23,6 +23,8 @@ FULLBAND = {
     "mel24_wide_bands": dict(n_mels=24, n_mfcc=12, f_min=50.0, f_max=8000.0),
     "fmax5k_wide_taps": dict(n_mels=32, f_max=5000.0),
     "mel2": dict(n_mels=2, n_mfcc=2, f_max=8000.0),
+    "mel72_idle_lanes_in_the_second_pass": dict(n_mels=72, n_mfcc=16, f_max=8000.0),      # 8 left-over bands: (band, frame) lanes
+    "mel100": dict(n_mels=100, n_mfcc=9, f_min=40.0, f_max=7800.0),                       # 36 left-over bands: four frames per lane
 }
 
 
