@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("COUGH_AMD_LIB") or os.path.join(HERE, "libcough_amd.s
 
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, 1, 2, 3, 4
 FEAT_NORMALIZE = 1
-PATH_GENERIC, PATH_TUNED, PATH_TUNED_FULLBAND = 0, 1, 2
+PATH_GENERIC, PATH_TUNED, PATH_TUNED_FULLBAND, PATH_TUNED_GEOMETRY = 0, 1, 2, 3
 SPEC_MAGNITUDE, SPEC_FULL_WINDOW = 1, 2
 DTYPE_FP32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 3
 DTYPES = {"fp32": DTYPE_FP32, "bf16_approx": DTYPE_BF16, "bf16x3": DTYPE_BF16X3}

@@ -138,13 +138,14 @@ static_assert(ST_X3_OFF % 16 == 0 && ST_IMG % 4 == 0 && ST_X3_OFF >= size_t(NMF)
 struct FullBank {
     int n_mels, n_mfcc, n_taps;
     int maxw[2];             // widest band of bands 0..63 / 64..127 (taps)
+    int n_frames, n_samples, hop;   // GEO instantiations: frames per clip (<= 128), samples per clip, hop length
     int cph, cph_pad, cw;    // MFCCs of the first thread half (ceil(n_mfcc / 2)); table rows per half (whole chunks); chunk width 4..7
     const int *lo, *hi, *off;   // [n_mels] first bin, end bin, offset of the band's taps in w
     const float* w;          // CSR taps, times 1/4 (the spectrum is formed as 2X)
     const float* dct;        // [2][cph_pad / cw chunks][n_mels][8] DCT-II (ortho): the cw coefficients of a chunk per mel band,
                              // zero-padded to 8 floats
 };
-constexpr size_t full_mel_bytes(int n_mels) { return (size_t(n_mels) * NFRAMES * 4 + 15) & ~size_t(15); }
+constexpr size_t full_mel_bytes(int n_mels, int n_frames = NFRAMES) { return (size_t(n_mels) * n_frames * 4 + 15) & ~size_t(15); }
 // FULL: a wave's transpose scratch interleaves its four frames -- element (row k, frame f, column n) at 65 k + 16 f + n, the
 // layout of the stand-alone STFT kernel (spectrogram.hip) -- in 1040 floats instead of 4 x 272; afterwards it holds the four
 // frames' power rows of 257 (+ 1 padding) bins at a pitch of 260.  768 bytes less per workgroup: an 80-band bank then still fits
@@ -153,8 +154,8 @@ constexpr int FX_ROW = FPW * 16 + 1, FX_WAVE = 16 * FX_ROW, FX_PROW = 260;
 static_assert(FPW * FX_PROW <= FX_WAVE && FX_PROW >= NFFT / 2 + 2 && FX_PROW % 2 == 0, "four power rows replace the transposes");
 constexpr size_t LDS_XCH_FULL = size_t(WAVES) * FX_WAVE * 4;   // 16640
 constexpr int FULL_MAX_MFCC = int(LDS_XCH_FULL / (size_t(2) * NFRAMES * 4));   // 20: MFCC + delta buffers alias the scratch
-constexpr size_t full_lds_bytes(int n_mels, int n_taps) {
-    return LDS_XCH_FULL + full_mel_bytes(n_mels) + LDS_RED + LDS_TW + ((size_t(n_taps) * 4 + 15) & ~size_t(15));
+constexpr size_t full_lds_bytes(int n_mels, int n_taps, int n_frames = NFRAMES) {
+    return LDS_XCH_FULL + full_mel_bytes(n_mels, n_frames) + LDS_RED + LDS_TW + ((size_t(n_taps) * 4 + 15) & ~size_t(15));
 }
 
 // PRE_EMPH: pre-emphasis is a separate instantiation (it never costs the shipped path registers).
@@ -173,16 +174,24 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps) {
 // PCS: the fused stem's mel rows are the PCEN values (use_pcen with a fused stem) -- a template parameter because the values
 // wait in 26 registers from the PCEN branch to the image build, which costs the shipped instantiation 1.3 % when it is a run-time
 // choice (same-box A/B, profiles/r05_bench_flags.txt).
-template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false, bool PCS = false>
-__global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
+// GEO (with FULL, no stem): run-time STFT geometry at n_fft = 512 -- any hop <= 256, window <= 512 (all 16 sample pairs of a
+// lane are live), segment length with up to 128 frames, i.e. other sample rates / window durations on the one-launch kernel
+// instead of the generic chain.  Samples arrive as 4-byte loads (no alignment contract), two workgroups per CU.
+template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false, bool PCS = false, bool GEO = false>
+__global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
     1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem, FullBank fbk,
     const float* __restrict__ full_dct /* = fbk.dct: read-only for the kernel's lifetime, so its wave-uniform loads are scalar */,
     float* __restrict__ peak_out /* [n] or nullptr: the clip's max |sample| under the fused normalise (the contrast path's scale) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nmel = FULL ? fbk.n_mels : NMEL, nmfcc = FULL ? fbk.n_mfcc : NMFCC, nmf = nmfcc * NFRAMES;
-    const size_t lds_mel = FULL ? full_mel_bytes(nmel) : LDS_MEL;
+    static_assert(!GEO || (FULL && STEM == 0 && !TALL && !PCS), "run-time geometry: full-band instantiations without a stem");
+    // frames per clip, four-frame groups, samples per clip, hop: compile-time constants unless GEO
+    const int NF = GEO ? fbk.n_frames : NFRAMES, NGR = GEO ? (fbk.n_frames + FPW - 1) / FPW : NGROUP;
+    const int NSMP = GEO ? fbk.n_samples : NS, HP = GEO ? fbk.hop : HOP;
+    constexpr int N1A = GEO ? 0 : 1, N1B = GEO ? 16 : 15;   // live sample pairs of a lane (window 400 in 512: pairs 1..14)
+    const int nmel = FULL ? fbk.n_mels : NMEL, nmfcc = FULL ? fbk.n_mfcc : NMFCC, nmf = nmfcc * NF;
+    const size_t lds_mel = FULL ? full_mel_bytes(nmel, NF) : LDS_MEL;
     constexpr size_t lds_xch = FULL ? LDS_XCH_FULL : LDS_XCH;
     float* xs = reinterpret_cast<float*>(smem);
     float* melbuf = reinterpret_cast<float*>(smem + lds_xch);
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long clip = blockIdx.x;
     const float* x = wav + clip * wav_stride;
-    float* o = out + clip * (long long)nfeat * NFRAMES;
+    float* o = out + clip * (long long)nfeat * NF;
     const bool wr = out != nullptr;   // features are materialised (always, unless the fused pipeline asks not to)
 
     K1_STAMP(0);
@@ -248,8 +257,25 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     // byte of the clip is requested from HBM once.
     auto load_group = [&](int g, float2 (&raw)[16]) {
         const int t_raw = FPW * g + fsub;
-        const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
-        const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
+        const int t = t_raw < NF ? t_raw : NF - 1;             // idle sub-frames redo the last frame
+        const int s0 = HP * t - PADL + 2 * j;                  // clip index of padded sample 2j of frame t
+        if constexpr (GEO) {
+            // frames whose whole 512-sample span lies inside the clip load directly, the others by reflected index (torch.stft
+            // center / reflect); 4-byte loads: hop and row stride are arbitrary
+            const bool plain = HP * (FPW * g) - PADL >= 0 && FPW * g + FPW - 1 < NF && HP * (FPW * g + FPW - 1) - PADL + NFFT <= NSMP;
+            if (plain) {   // wave-uniform
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) raw[n1] = make_float2(x[s0 + 32 * n1], x[s0 + 32 * n1 + 1]);
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    int i0 = s0 + 32 * n1, i1 = i0 + 1;
+                    i0 = i0 < 0 ? -i0 : (i0 >= NSMP ? 2 * (NSMP - 1) - i0 : i0);
+                    i1 = i1 < 0 ? -i1 : (i1 >= NSMP ? 2 * (NSMP - 1) - i1 : i1);
+                    raw[n1] = make_float2(x[i0], x[i1]);
+                }
+            }
+        } else
         if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform
             K1_MARK("WEIGHT 0.885 (23 of 26 groups: frames inside the clip)");
 #pragma unroll
@@ -275,24 +301,26 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         float w_re[16], w_im[16];   // window taps of this lane's samples (zero taps of the padded window are never loaded)
         const int jw = 2 * j;
 #pragma unroll
-        for (int n1 = 1; n1 < 15; ++n1) {
+        for (int n1 = N1A; n1 < N1B; ++n1) {
             w_re[n1] = tb->win[32 * n1 + jw] * ws1 * ws2;
             w_im[n1] = tb->win[32 * n1 + jw + 1] * ws1 * ws2;
         }
         load_group(wave, raw);
 
         K1_MARK("LOOP 6.5 P1 four-frame groups per wave");
-        for (int g = wave; g < NGROUP; g += WAVES) {
+        for (int g = wave; g < NGR; g += WAVES) {
             K1_MARK("PHASE P1 peak + window multiply + next group's loads");
             const int t_raw = FPW * g + fsub;
-            const int t = t_raw < NFRAMES ? t_raw : NFRAMES - 1;   // idle sub-frames redo the last frame
-            const int s0 = HOP * t - PADL + 2 * j;                 // clip index of padded sample 2j of frame t
+            const int t = t_raw < NF ? t_raw : NF - 1;             // idle sub-frames redo the last frame
+            const int s0 = HP * t - PADL + 2 * j;                  // clip index of padded sample 2j of frame t
             float2 a[16];
-            a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
-            a[15] = make_float2(0.f, 0.f);
+            if constexpr (!GEO) {
+                a[0] = make_float2(0.f, 0.f);    // window is zero on samples [0,56) and [456,512)
+                a[15] = make_float2(0.f, 0.f);
+            }
             if constexpr (!PRE_EMPH) {
 #pragma unroll
-                for (int n1 = 1; n1 < 15; ++n1) {
+                for (int n1 = N1A; n1 < N1B; ++n1) {
                     peak = fmaxf(peak, fmaxf(fabsf(raw[n1].x), fabsf(raw[n1].y)));   // one v_max3_f32 with |.| modifiers
                     a[n1] = make_float2(raw[n1].x * w_re[n1], raw[n1].y * w_im[n1]);
                 }
@@ -300,7 +328,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             if constexpr (PRE_EMPH) {
                 // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the reflect padding as the
                 // reference does; no FMA contraction (mul_rn, __fsub_rn).  The peak is of x, not of the emphasised signal.
-                if (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
+                if (!GEO && FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
                     // x[i0 - 1] is the second sample of the lane to the left (row_ror:1); lane 0 takes lane 15's pair of the
                     // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does)
                     float carry = 0.f;
@@ -314,12 +342,12 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                         a[n1] = make_float2(__fsub_rn(x0, mul_rn(pre_coef, left)) * w_re[n1],
                                             __fsub_rn(x1, mul_rn(pre_coef, x0)) * w_im[n1]);
                     }
-                } else {   // reflected edge frames (3 of 26 groups): the left neighbour in CLIP order, by re-gather
+                } else {   // reflected edge frames (3 of 26 groups; GEO: every group): the left neighbour in CLIP order, by re-gather
 #pragma unroll
-                    for (int n1 = 1; n1 < 15; ++n1) {
+                    for (int n1 = N1A; n1 < N1B; ++n1) {
                         int i0 = s0 + 32 * n1, i1 = i0 + 1;
-                        i0 = i0 < 0 ? -i0 : (i0 >= NS ? 2 * (NS - 1) - i0 : i0);
-                        i1 = i1 < 0 ? -i1 : (i1 >= NS ? 2 * (NS - 1) - i1 : i1);
+                        i0 = i0 < 0 ? -i0 : (i0 >= NSMP ? 2 * (NSMP - 1) - i0 : i0);
+                        i1 = i1 < 0 ? -i1 : (i1 >= NSMP ? 2 * (NSMP - 1) - i1 : i1);
                         const float p0 = i0 > 0 ? mul_rn(pre_coef, x[i0 - 1]) : 0.f;
                         const float p1 = i1 > 0 ? mul_rn(pre_coef, x[i1 - 1]) : 0.f;
                         const float x0 = raw[n1].x, x1 = raw[n1].y;
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             }
             // the raw registers are free again: the next group's samples start moving now and land while
             // this group's FFT / mel / log run
-            if (g + WAVES < NGROUP) load_group(g + WAVES, raw);
+            if (g + WAVES < NGR) load_group(g + WAVES, raw);
             K1_MARK("PHASE P1 radix-16 #1");
             dft16(a);
             K1_MARK("PHASE P1 twiddle (LDS table) complex multiply");
@@ -387,11 +415,11 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 #pragma unroll
                     for (int q = 0; q < MAXW; ++q) acc += mw[q] * p[q];
                     const int tf = FPW * g + f;
-                    if (tf < NFRAMES) {
+                    if (tf < NF) {
                         // raw dB = 10*log10(acc) = 3.0103*log2(acc) on the hardware log2 (|error| ~1e-6 dB);
                         // -inf for 0: amin and normalisation are applied in P2
                         const float db = 3.01029995663981195f * __log2f(acc);
-                        melbuf[lane * NFRAMES + tf] = db;
+                        melbuf[lane * NF + tf] = db;
                         run_max = fmaxf(run_max, db);
                         chk = fmaf(acc, 0.f, chk);   // NaN / Inf power (a non-finite sample under the frame, f32 overflow) -> NaN, sticky
                     }
@@ -452,9 +480,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
 #pragma unroll
                     for (int f = 0; f < FPL; ++f) {
                         const int tf = FPW * g + f0 + f;
-                        if (mb >= 0 && tf < NFRAMES) {
+                        if (mb >= 0 && tf < NF) {
                             const float db = 3.01029995663981195f * __log2f(acc[f]);   // as above
-                            melbuf[mb * NFRAMES + tf] = db;
+                            melbuf[mb * NF + tf] = db;
                             run_max = fmaxf(run_max, db);
                             chk = fmaf(acc[f], 0.f, chk);
                         }
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         const float nanv = __builtin_nanf("");
         const int rows = nmel + (delta_delta == 2 ? 0 : (delta_delta == 1 ? 3 : 2) * nmfcc);
         if (wr)
-            for (int i = tid; i < rows * NFRAMES; i += THREADS) o[i] = nanv;
+            for (int i = tid; i < rows * NF; i += THREADS) o[i] = nanv;
         if constexpr (STEM != 0)
             if (tid == 0) stem.nanflag[clip] = 1;   // a1 is left unwritten: the head overwrites this clip's logits
         return;
@@ -527,12 +555,12 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         // min-max-normalised (mel / (1e-6 + smooth)^0.98 + 2)^0.5 - 2^0.5, smooth = 10-frame moving average
         // (zero padded, always / 10).  Works on the (peak-normalised) mel POWER, rebuilt from the raw dB
         // buffer; thread = (band, quarter of the frames) slides the window over its own 36 powers.
-        const int m = tid >> 2, t0 = (tid & 3) * 26, t1 = t0 + 26 < NFRAMES ? t0 + 26 : NFRAMES;
+        const int m = tid >> 2, t0 = (tid & 3) * 26, t1 = t0 + 26 < NF ? t0 + 26 : NF;   // NF <= 104
         float p[36], pv[26];
 #pragma unroll
         for (int k = 0; k < 36; ++k) {
             const int u = t0 - 5 + k;
-            p[k] = (u >= 0 && u < NFRAMES) ? exp2f((melbuf[m * NFRAMES + u] - shift) * 0.33219280948873623f) : 0.f;
+            p[k] = (u >= 0 && u < NF) ? exp2f((melbuf[m * NF + u] - shift) * 0.33219280948873623f) : 0.f;
         }
         float lmin = INFINITY, lmax = -INFINITY;
         float s2[35];   // pair sums shared by neighbouring windows: 5 adds per window instead of 10
@@ -552,7 +580,7 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         if (wr) {
 #pragma unroll
             for (int k = 0; k < 26; ++k)
-                if (t0 + k < t1) o[m * NFRAMES + t0 + k] = (pv[k] - mn) * rng;
+                if (t0 + k < t1) o[m * NF + t0 + k] = (pv[k] - mn) * rng;
         }
         if constexpr (PCS) {
 #pragma unroll
@@ -562,6 +590,13 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
     }
     K1_MARK("ENDSKIP");
     K1_MARK("PHASE P2 floor + mel rows store");
+    if constexpr (GEO) {   // n_mels x frames may be odd and the clip's rows 4-byte aligned only: one element per step
+        for (int i = tid; i < nmel * NF; i += THREADS) {
+            const float d = fmaxf(fmaxf(melbuf[i] - shift, -100.0f), floor_db);
+            melbuf[i] = d;
+            if (wr_mel) o[i] = fminf(fmaxf((d + 80.0f) * 0.0125f, 0.f), 1.f);
+        }
+    } else
     for (int i2 = tid; i2 < nmel * NFRAMES / 2; i2 += THREADS) {   // 2 elements / thread: 8-byte stores (n_mels is even)
         float2 d = reinterpret_cast<float2*>(melbuf)[i2];
         d.x = fmaxf(fmaxf(d.x - shift, -100.0f), floor_db);
@@ -592,19 +627,19 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
                 float acc[CW];
 #pragma unroll
                 for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.f;
-                if (tt < NFRAMES) {
+                if (tt < NF) {
                     // the chunk's coefficients of one mel band are 8 consecutive floats: one s_load_dwordx8 per band (rows at a
                     // run-time stride of n_mels made every coefficient a scalar load of its own: 3x the shipped DCT phase)
                     const float* drow = full_dct + (size_t(chalf) * fbk.cph_pad + cq) / CW * size_t(nmel) * 8;
 #pragma unroll 8
                     for (int m = 0; m < nmel; ++m) {
-                        const float v = melbuf[m * NFRAMES + tt];
+                        const float v = melbuf[m * NF + tt];
 #pragma unroll
                         for (int cc = 0; cc < CW; ++cc) acc[cc] = fmaf(drow[m * 8 + cc], v, acc[cc]);
                     }
 #pragma unroll
                     for (int cc = 0; cc < CW; ++cc)
-                        if (cq + cc < nch) mf[(cbase + cq + cc) * NFRAMES + tt] = acc[cc];
+                        if (cq + cc < nch) mf[(cbase + cq + cc) * NF + tt] = acc[cc];
                 }
             }
         };
@@ -862,12 +897,12 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
             }
         }
     }
-    float* o_mfcc = o + nmel * NFRAMES;
+    float* o_mfcc = o + nmel * NF;
     float* o_delta = o_mfcc + nmf;
     for (int item = tid; item < nmf; item += THREADS) {
-        const int c = item / NFRAMES, t = item - c * NFRAMES;
-        const float* row = mf + c * NFRAMES;
-        const float d = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;   // :353-355
+        const int c = item / NF, t = item - c * NF;
+        const float* row = mf + c * NF;
+        const float d = (row[t < NF - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;   // :353-355
         if (wr) {
             o_mfcc[item] = row[t];
             o_delta[item] = d;
@@ -883,9 +918,9 @@ __global__ __launch_bounds__(THREADS, 3) void featurize_kernel(
         __syncthreads();
         float* o_dd = o_delta + nmf;
         for (int item = tid; item < nmf; item += THREADS) {
-            const int c = item / NFRAMES, t = item - c * NFRAMES;
-            const float* row = dl + c * NFRAMES;
-            o_dd[item] = (row[t < NFRAMES - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
+            const int c = item / NF, t = item - c * NF;
+            const float* row = dl + c * NF;
+            o_dd[item] = (row[t < NF - 1 ? t + 1 : t] - row[t > 0 ? t - 1 : 0]) / 2.0f;
         }
     }
     if constexpr (STEM != 0) {
@@ -990,7 +1025,8 @@ struct cough_featurizer {
     cough::ContrastCfg contrast;   // n_bands == 0: no spectral-contrast rows
     int n_cus;           // compute units of the device the featuriser was created on
     int kind;            // the one-launch kernel that serves the constructor's segment length: 0 none (generic chain), 1 the
-                         // shipped sparse-filterbank instantiations, 2 the full-band ones (any filterbank, run-time n_mels / n_mfcc)
+                         // shipped sparse-filterbank instantiations, 2 the full-band ones (any filterbank, run-time n_mels / n_mfcc),
+                         // 3 the full-band ones with a run-time STFT geometry (n_fft 512, hop <= 256, <= 128 frames)
     char* d_full;        // kind 2: CSR filterbank + DCT rows (one blob)
     cough::FullBank full;
     size_t full_lds;     // kind 2: dynamic LDS of a workgroup
@@ -1023,8 +1059,15 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     std::vector<int> f_lo, f_hi, f_off;
     std::vector<float> f_taps, f_dct;
     FullBank fb{};
+    // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
+    // lengths of up to 128 frames; no contrast rows (their STFT passes are built for the shipped geometry)
+    const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
+    const bool geo_ok = !stft_ok && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
+                        cfg->hop_length <= NFFT / 2 && cfg->segment_samples > NFFT / 2 && geo_frames <= 128 &&
+                        !cfg->use_spectral_contrast && (!cfg->use_pcen || geo_frames <= 104) &&
+                        (!cfg->use_mfcc || 2 * cfg->n_mfcc * geo_frames * 4 <= int(LDS_XCH_FULL));
     bool full = false;
-    if (!tuned && stft_ok && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
+    if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
         (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= FULL_MAX_MFCC && cfg->n_mfcc <= cfg->n_mels)) &&
         (!cfg->use_pcen || cfg->n_mels == NMEL)) {
         const int nm = cfg->n_mels, nc = cfg->use_mfcc ? cfg->n_mfcc : 1;
@@ -1060,7 +1103,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                 for (int m = 0; m < nm; ++m)
                     f_dct[((size_t(half) * chunks_per_half + r / fb.cw) * nm + m) * 8 + r % fb.cw] = dct[m * nc + c];
             }
-        full = full_lds_bytes(nm, fb.n_taps) <= 80 * 1024;   // at least two workgroups per CU
+        fb.n_frames = stft_ok ? NFRAMES : geo_frames;
+        fb.n_samples = cfg->segment_samples;
+        fb.hop = cfg->hop_length;
+        full = full_lds_bytes(nm, fb.n_taps, fb.n_frames) <= 80 * 1024;   // at least two workgroups per CU
     }
     if (cfg->use_spectral_contrast) {
         COUGH_REQUIRE(cfg->n_contrast_bands >= 1 && cfg->n_contrast_bands <= COUGH_MAX_CONTRAST_BANDS, COUGH_EUNSUPPORTED,
@@ -1076,9 +1122,9 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     FeatTables& t = host[0];
     std::memset(&t, 0, sizeof(t));
     const double PI = 3.14159265358979323846;
-    if (stft_ok) {   // the STFT tables of the one-launch kernels and of the persistent STFT kernel (spectrogram.hip)
-        const int left = (NFFT - WIN) / 2;
-        for (int n = 0; n < WIN; ++n) t.win[left + n] = window[n];
+    if (stft_ok || (full && geo_ok)) {   // the STFT tables of the one-launch kernels and of the persistent STFT kernel (spectrogram.hip)
+        const int left = (NFFT - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
+        for (int n = 0; n < cfg->win_length; ++n) t.win[left + n] = window[n];
         for (int jj = 0; jj < 16; ++jj)
             for (int k1 = 0; k1 < 16; ++k1) {
                 const double a = -2.0 * PI * double(jj * k1) / 256.0;
@@ -1110,10 +1156,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
     f->gen = gen;
-    f->kind = tuned ? 1 : full ? 2 : 0;
+    f->kind = tuned ? 1 : full ? (stft_ok ? 2 : 3) : 0;
     f->d_full = nullptr;
     f->full = fb;
-    f->full_lds = full ? full_lds_bytes(fb.n_mels, fb.n_taps) : 0;
+    f->full_lds = full ? full_lds_bytes(fb.n_mels, fb.n_taps, fb.n_frames) : 0;
     f->nbase = cfg->use_mfcc ? cfg->n_mels + 2 * cfg->n_mfcc + (cfg->use_delta_delta ? cfg->n_mfcc : 0) : cfg->n_mels;
     f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
     f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
@@ -1156,7 +1202,9 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                              reinterpret_cast<const void*>(featurize_kernel<false, 2, true, false, true>),
                              reinterpret_cast<const void*>(featurize_kernel<false, 2, true, true, true>),
                              reinterpret_cast<const void*>(featurize_kernel<true, 2, true, false, true>),
-                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true, true>)};
+                             reinterpret_cast<const void*>(featurize_kernel<true, 2, true, true, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<false, 0, true, false, false, true>),
+                             reinterpret_cast<const void*>(featurize_kernel<true, 0, true, false, false, true>)};
         for (const void* fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
@@ -1204,10 +1252,16 @@ StftView featurizer_stft_view(const cough_featurizer* f) {
 }
 int featurizer_num_features(const cough_featurizer* f) { return f->nfeat; }
 const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
-bool featurizer_tuned(const cough_featurizer* f, int n_samples) { return f->kind != 0 && (n_samples <= 0 || n_samples == NS); }
+bool featurizer_tuned(const cough_featurizer* f, int n_samples) {
+    return f->kind != 0 && (n_samples <= 0 || n_samples == f->cfg.segment_samples);
+}
+bool featurizer_shipped_stft(const cough_featurizer* f, int n_samples) {   // the persistent STFT kernel's geometry
+    return (f->kind == 1 || f->kind == 2) && (n_samples <= 0 || n_samples == NS);
+}
 bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
     // a one-launch kernel writing the whole image (no contrast rows), 64 mel + 13 MFCC rows
-    if (f->kind == 0 || f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->nfeat != f->nbase) return false;
+    if (f->kind == 0 || f->kind == 3 || f->cfg.n_mels != NMEL || f->cfg.n_mfcc != NMFCC || !f->cfg.use_mfcc || f->nfeat != f->nbase)
+        return false;
     // split-bf16 stem: the 90-row layout, or the 103-row layout of the delta-delta flag (two halves); shipped or full-band
     // filterbank, with or without pre-emphasis / PCEN.  The approximate single-bf16 stem exists for the shipped 90-row set only.
     if (x3) return f->nfeat == ST_H || (f->nfeat == ST_H + NMFCC && f->cfg.use_delta_delta);
@@ -1229,8 +1283,12 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, n_samples, d_feat, f->nfeat, f->nbase, n_clips,
                              (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0, d_workspace, workspace_bytes, stream);
     }
-    COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
-                  COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
+    if (f->kind == 3)
+        COUGH_REQUIRE(wav_stride >= f->cfg.segment_samples, COUGH_EINVAL, "cough_featurize: row stride %lld < segment of %d samples",
+                      wav_stride, f->cfg.segment_samples);
+    else
+        COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
+                      COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
     COUGH_REQUIRE(!stem || featurizer_stem_fusable(f, stem->x3 != 0), COUGH_EUNSUPPORTED,
                   "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
@@ -1247,7 +1305,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         peak_out = contrast_peaks(d_workspace, n_clips);
     }
     // one instantiation per (pre-emphasis, stem, full-band filterbank, 103-row stem); everything else is a run-time argument
-    const bool full = f->kind == 2, pe = f->cfg.use_pre_emphasis != 0;
+    const bool full = f->kind >= 2, pe = f->cfg.use_pre_emphasis != 0;
     const size_t lds = full ? f->full_lds : LDS_TOTAL;
     const FullBank& fbk = full ? f->full : nofb;
     const float* fdct = full ? f->full.dct : nullptr;
@@ -1270,6 +1328,9 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         }
     } else if (stem) {        // approximate single-bf16 stem: shipped filterbank, no pre-emphasis (featurizer_stem_fusable)
         go(featurize_kernel<false, 1>, *stem, 0);
+    } else if (f->kind == 3) {   // run-time STFT geometry
+        if (pe) go(featurize_kernel<true, 0, true, false, false, true>, none, f->cfg.use_pcen);
+        else go(featurize_kernel<false, 0, true, false, false, true>, none, f->cfg.use_pcen);
     } else if (full) {
         if (pe) go(featurize_kernel<true, 0, true>, none, f->cfg.use_pcen);
         else go(featurize_kernel<false, 0, true>, none, f->cfg.use_pcen);

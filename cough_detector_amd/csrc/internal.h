@@ -65,6 +65,7 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
                   void* d_workspace, size_t workspace_bytes, hipStream_t stream);
 const GenFeat* featurizer_generic(const cough_featurizer* f);   // every featuriser has the generic chain's tables
 bool featurizer_tuned(const cough_featurizer* f, int n_samples = 0);   // the one-launch kernel serves waveforms of this length
+bool featurizer_shipped_stft(const cough_featurizer* f, int n_samples = 0);   // ... at the shipped STFT geometry (persistent STFT kernel)
 int launch_stft(const StftView& v, const float* d_wav, long long wav_stride, float* d_spec, int n_clips, int flags,
                 hipStream_t stream);
 

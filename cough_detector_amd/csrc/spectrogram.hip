@@ -616,7 +616,7 @@ extern "C" int cough_spectrogram_any(const cough_featurizer* f, const float* d_w
     COUGH_REQUIRE(n_clips >= 0 && n_samples >= 0, COUGH_EINVAL, "cough_spectrogram: n_clips < 0 or n_samples < 0");
     COUGH_REQUIRE((flags & ~(COUGH_SPEC_MAGNITUDE | COUGH_SPEC_FULL_WINDOW)) == 0, COUGH_EINVAL,
                   "cough_spectrogram: unknown flag bits 0x%x", flags);
-    if (!featurizer_tuned(f, n_samples)) {   // a geometry / a waveform length the persistent kernel is not built for
+    if (!featurizer_shipped_stft(f, n_samples)) {   // a geometry / a waveform length the persistent kernel is not built for
         if (n_clips == 0) return COUGH_OK;
         return gen_spectrogram(featurizer_generic(f), d_wav, wav_stride, n_samples, d_spec, n_clips, flags,
                                static_cast<hipStream_t>(stream));

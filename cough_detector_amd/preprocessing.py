@@ -142,8 +142,9 @@ class AudioPreprocessor:
 
     def kernel_path(self) -> str:
         """Which kernels featurise ``segment_samples`` windows: "tuned" (one launch, the shipped sparse filterbank),
-        "tuned_fullband" (one launch, any filterbank at the shipped STFT geometry) or "generic" (the kernel chain)."""
-        return ("generic", "tuned", "tuned_fullband")[_lib.load().cough_featurizer_path(self._native())]
+        "tuned_fullband" (one launch, any filterbank at the shipped STFT geometry), "tuned_geometry" (one launch, n_fft 512 with
+        another hop / window / sample rate / segment of up to 128 frames) or "generic" (the kernel chain)."""
+        return ("generic", "tuned", "tuned_fullband", "tuned_geometry")[_lib.load().cough_featurizer_path(self._native())]
 
     def _check_length(self, n_samples: int) -> None:
         if n_samples <= self.n_fft // 2:

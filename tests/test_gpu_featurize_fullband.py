@@ -53,7 +53,13 @@ def test_which_constructor_calls_land_on_which_kernels():
     # outside: odd band counts, more than 20 MFCCs (their buffers alias the transpose scratch), PCEN off 64 bands, other STFTs
     assert path(n_mels=63, f_max=8000.0) == "generic" and path(n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
     assert path(n_mels=80, f_max=8000.0, use_pcen=True) == "generic"
-    assert path(hop_length=200) == "generic" and path(n_fft=400) == "generic" and path(segment_duration=2.0) == "generic"
+    # n_fft = 512 with another hop / window / sample rate / segment of <= 128 frames: the full-band kernel with a run-time geometry
+    assert path(hop_length=200) == "tuned_geometry" and path(segment_duration=0.5) == "tuned_geometry"
+    assert path(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441) == "tuned_geometry"
+    assert path(hop_length=128, win_length=512) == "tuned_geometry" and path(win_length=37, hop_length=77, n_mels=20, segment_duration=0.5) == "tuned_geometry"
+    assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=4) == "generic"      # contrast rows: shipped STFT only
+    assert path(hop_length=300) == "generic" and path(hop_length=100) == "generic"                 # hop > 256; 161 frames > 128
+    assert path(n_fft=400) == "generic" and path(segment_duration=2.0) == "generic"
 
 
 @pytest.mark.parametrize("name", sorted(FULLBAND))

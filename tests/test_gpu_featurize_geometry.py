@@ -1,0 +1,164 @@
+"""The one-launch featuriser with a run-time STFT geometry (featurize_kernel<..., GEO = true>, COUGH_PATH_TUNED_GEOMETRY) vs the
+CPU oracle.
+
+``AudioPreprocessor(sample_rate=..., hop_length=..., win_length=..., segment_duration=...)`` at n_fft = 512
+(``/root/reference/src/preprocessing.py:32-51, 94-136``; ``RealtimePreprocessor(window_duration=...)`` :559-580) used to leave
+the one-launch kernel for the generic kernel chain as soon as the hop, the window or the segment length differed from the shipped
+ones.  The GEO instantiations take hop (<= 256), window (<= 512), segment length (<= 128 frames) and the filterbank at run time;
+contrast rows and longer segments stay on the generic chain."""
+import numpy as np
+import pytest
+import torch
+
+import cough_detector_amd as cda
+from oracle import featurizer as ofeat
+from parity import FEAT_TOL, SHIPPED
+from test_oracle_featurizer import geometry_clip
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(sample_rate=16000, n_mels=64, n_fft=512, hop_length=160, win_length=400, f_min=100.0, f_max=4000.0, n_mfcc=13)
+GEO = {      # name -> (geometry overrides, segment seconds)
+    "hop200_40mel": (dict(hop_length=200, n_mels=40), 1.0),
+    "half_second": (dict(), 0.5),
+    "quarter_second_fmax8k": (dict(f_max=8000.0), 0.25),
+    "hop128_win512_126_frames": (dict(hop_length=128, win_length=512), 1.0),
+    "sr22050_hop220_win441": (dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441), 1.0),
+    "sr8000_two_seconds_hop256": (dict(sample_rate=8000, f_max=4000.0, hop_length=256, win_length=512), 2.0),
+    "odd_hop77_win37_20mel": (dict(hop_length=77, win_length=37, n_mels=20), 0.5),
+    "one_tap_window": (dict(win_length=1), 0.25),
+    "hop3_107_frames": (dict(hop_length=3, win_length=64, n_mels=32), 0.02),
+    "shortest_segment_257_samples": (dict(hop_length=16, win_length=128, sample_rate=25700, f_max=8000.0), 0.01),
+    "mel80_mfcc20_hop200": (dict(n_mels=80, n_mfcc=20, f_max=8000.0, hop_length=200), 1.0),
+    "mel100_127_frames": (dict(n_mels=100, n_mfcc=16, f_min=0.0, f_max=8000.0, hop_length=126, win_length=512), 1.0),
+    "mel2_128_frames": (dict(n_mels=2, n_mfcc=2, f_max=8000.0, hop_length=125, win_length=250), 0.9925),
+}
+
+
+def _errors(got, ref, n_mels):
+    got, ref = got.detach().cpu().float(), ref.detach().cpu().float()
+    mel = (got[..., :n_mels, :] - ref[..., :n_mels, :]).abs().max().item()
+    d = (got[..., n_mels:, :] - ref[..., n_mels:, :]).abs()
+    return mel, ((d / ref[..., n_mels:, :].abs().clamp(min=1.0)).max().item() if d.numel() else 0.0)
+
+
+def _make(name, **flags):
+    over, seconds = GEO[name]
+    g = {**BASE, **over}
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **g, **{**SHIPPED, **flags})
+    return pre, g
+
+
+@pytest.mark.parametrize("name", sorted(GEO))
+def test_runtime_geometry_against_oracle(name):
+    pre, g = _make(name)
+    assert pre.kernel_path() == "tuned_geometry"
+    n, nm = pre.segment_samples, g["n_mels"]
+    T = 1 + n // g["hop_length"]
+    assert n > 256 and T <= 128
+    w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(12)]))
+    w[7] = 0.0                                                       # digital silence: amin clamp, no NaN
+    w[8] = 0.25                                                      # DC: only the reflect padding and the window shape it
+    w[9, : n // 2] = 0.0                                             # half silent: the top_db floor is active
+    kw = ofeat.geometry_kwargs(**g)
+    for normalize in (False, True):
+        got = pre.featurize_batch(w.cuda(), normalize=normalize)
+        ref = ofeat.extract_features_batch(w, normalize_first=normalize, **kw)
+        assert got.shape == ref.shape == (12, nm + 2 * g["n_mfcc"], T) == (12, pre.get_num_features(), pre._frames(n))
+        keep = [i for i in range(12) if i != 8]                      # DC is ill-conditioned in float32 (tests/parity.py)
+        mel, rel = _errors(got[keep], ref[keep], nm)
+        print(f"{name} normalize={normalize}: {tuple(got.shape)} mel abs {mel:.2e}, mfcc/delta rel {rel:.2e}")
+        assert torch.isfinite(got).all() and mel < FEAT_TOL and rel < 2 * FEAT_TOL
+        melh, relh = _errors(got[8:9], ref[8:9], nm)
+        assert melh < 2e-2 and relh < 2e-2
+        assert torch.all(got[7, :nm] == 0)
+        # batch invariance: every reduction is per clip
+        assert torch.equal(pre.featurize_batch(w[3:4].cuda(), normalize=normalize)[0], got[3])
+    # another length through the same handle goes down the generic chain and comes back (the length is a launch parameter)
+    other = torch.from_numpy(np.stack([geometry_clip(s, n + 300) for s in (0, 1)]))
+    f2 = pre.extract_features(other.cuda())
+    mel, rel = _errors(f2, ofeat.extract_features_batch(other, **kw), nm)
+    assert f2.shape[2] == 1 + (n + 300) // g["hop_length"] and mel < FEAT_TOL and rel < 2 * FEAT_TOL
+    assert torch.equal(pre.featurize_batch(w.cuda(), normalize=True), got)
+
+
+@pytest.mark.parametrize("flags", [dict(use_pre_emphasis=True), dict(use_delta_delta=True), dict(use_pcen=True), dict(use_mfcc=False),
+                                   dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)],
+                         ids=["preemph", "dd", "pcen", "no_mfcc", "preemph_dd_pcen"])
+@pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel"])
+def test_runtime_geometry_flags(name, flags):
+    pre, g = _make(name, **flags)
+    kw = {**SHIPPED, **flags}
+    n, nm = pre.segment_samples, g["n_mels"]
+    T = 1 + n // g["hop_length"]
+    # PCEN keeps its values in registers across 104 frames at most and is built for 64 bands: beyond, the generic chain
+    want = "generic" if flags.get("use_pcen") and (T > 104 or nm != 64) else "tuned_geometry"
+    assert pre.kernel_path() == want
+    w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(6)]))
+    got = pre.featurize_batch(w.cuda(), normalize=True)
+    ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g), **kw)
+    assert got.shape == ref.shape == (6, pre.get_num_features(), T)
+    mel, rel = _errors(got, ref, nm)
+    print(f"{name} {flags} [{want}]: mel abs {mel:.2e}, rest rel {rel:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL
+
+
+def test_what_stays_on_the_generic_chain():
+    def path(seconds=1.0, **kw):
+        return cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **{**BASE, **SHIPPED, **kw}).kernel_path()
+    assert path(hop_length=257) == "generic"                                       # frames would not overlap the packed pairs
+    assert path(hop_length=100) == "generic" and path(2.0) == "generic"            # 161 / 201 frames
+    assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "generic"
+    assert path(hop_length=200, n_mels=63) == "generic" and path(hop_length=200, n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
+    assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
+    assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS
+    assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "generic"                 # 2 x 20 x 127 MFCC cells
+    assert path(hop_length=126, win_length=512, n_mfcc=16, f_max=8000.0) == "tuned_geometry"
+
+
+def test_runtime_geometry_engine_windows(tmp_path):
+    """RealtimePreprocessor(window_duration=0.5) rebuilt by the engine from a checkpoint's config (inference.py:89-108): the
+    0.5 s windows take the one-launch kernel; probabilities and detections vs the CPU engine oracle."""
+    from cough_detector_amd import synth
+    from oracle import engine as oengine
+    from parity import realistic_state_dict
+    sd = realistic_state_dict(11)
+    cfg = dict(model_type="residual", sample_rate=16000, n_mels=64, n_fft=512, hop_length=160, win_length=400, f_min=100.0,
+               f_max=4000.0, segment_duration=0.5, n_mfcc=13, use_mfcc=True, use_pcen=False, use_pre_emphasis=False,
+               pre_emphasis_coef=0.97, use_delta_delta=False, use_spectral_contrast=False, n_contrast_bands=6)
+    path = str(tmp_path / "half_second.pt")
+    torch.save({"model_state_dict": sd, "config": cfg}, path)
+    now = {"t": 0.0}
+    eng = cda.CoughDetectorInference(path, confidence_threshold=0.5, smoothing_window=3, debounce_seconds=0.5, verbose=False,
+                                     clock=lambda: now["t"])
+    assert eng.preprocessor.window_samples == 8000 and eng.preprocessor.kernel_path() == "tuned_geometry"
+    ref = oengine.EngineOracle(sd, 0.5, 3, 0.5, clock=lambda: now["t"])
+    ref.windower = ofeat.RealtimeWindowerOracle(window_duration=0.5, hop_duration=0.25)
+    stream = synth.make_stream(9, 4.0)
+    hits, ref_hits = [], []
+    for i in range(0, len(stream), 1600):
+        now["t"] = (i + 1600) / 16000.0
+        a, b = eng.process_audio_chunk(stream[i:i + 1600]), ref.process_audio_chunk(stream[i:i + 1600])
+        hits.append(a is not None)
+        ref_hits.append(b is not None)
+    assert len(eng.window_probs) == len(ref.window_probs) > 10
+    assert np.abs(np.array(eng.window_probs) - np.array(ref.window_probs)).max() < 1e-3
+    assert hits == ref_hits
+
+
+def test_runtime_geometry_full_size_batch_properties():
+    """B = 4096 at 22.05 kHz through size-independent properties: batch invariance, mel rows in [0, 1], z-scored rows mean 0 /
+    unbiased std 1 per clip, delta rows = central difference of the stored MFCC rows."""
+    pre, g = _make("sr22050_hop220_win441")
+    from cough_detector_amd import synth
+    base = synth.device_clips(0, 4096)
+    w = torch.cat([base, base[:, :6050].flip(1)], dim=1).contiguous()            # 22 050 samples per clip
+    f = pre.featurize_batch(w, normalize=True)
+    assert f.shape == (4096, 90, 101) and torch.isfinite(f).all()
+    assert torch.equal(pre.featurize_batch(w[1000:1006], normalize=True), f[1000:1006])
+    mel, mf, dl = f[:, :64], f[:, 64:77], f[:, 77:90]
+    assert mel.min().item() >= 0.0 and mel.max().item() <= 1.0
+    flat = mf.reshape(4096, -1)
+    assert flat.mean(dim=1).abs().max().item() < 1e-4 and (flat.std(dim=1) - 1).abs().max().item() < 1e-4
+    pad = torch.nn.functional.pad(mf, (1, 1), mode="replicate")
+    assert torch.equal(dl, (pad[:, :, 2:] - pad[:, :, :-2]) / 2)

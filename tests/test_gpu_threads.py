@@ -112,9 +112,9 @@ def test_two_threads_share_immutable_handles_on_separate_streams():
     assert results == [True, True]
 
 
-@pytest.mark.parametrize("kw", [dict(hop_length=200, n_mels=40), dict(use_spectral_contrast=True, n_contrast_bands=4),
-                                dict(f_max=8000.0, n_mels=80, n_mfcc=20)],
-                         ids=["generic_chain", "contrast_rows", "fullband"])
+@pytest.mark.parametrize("kw", [dict(n_fft=400, n_mels=40), dict(hop_length=200, n_mels=40),
+                                dict(use_spectral_contrast=True, n_contrast_bands=4), dict(f_max=8000.0, n_mels=80, n_mfcc=20)],
+                         ids=["generic_chain", "runtime_geometry", "contrast_rows", "fullband"])
 def test_two_threads_share_one_preprocessor_that_needs_scratch(kw):
     """the generic chain and the contrast rows need a workspace; one AudioPreprocessor shared by two threads on two
     streams must give each launch scratch of its own (keyed by stream) -- every result bit-identical to the serial one, and a

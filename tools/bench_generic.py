@@ -17,6 +17,9 @@ CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
          ("2 s windows (201 frames)", dict(segment_duration=2.0), 2048),
          ("0.5 s windows (51 frames)", dict(segment_duration=0.5), 8192),
          ("22.05 kHz, hop 220, win 441", dict(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441), 4096),
+         ("hop 200 (81 frames)", dict(hop_length=200), 4096),
+         ("hop 128 / win 512 (126 frames)", dict(hop_length=128, win_length=512), 4096),
+         ("hop 100 (161 frames: generic chain)", dict(hop_length=100), 4096),
          ("n_fft 1024, win 400 (radix-4 Stockham kernel)", dict(n_fft=1024), 4096),
          ("n_fft 256, win 256, hop 128", dict(n_fft=256, win_length=256, hop_length=128), 4096),
          ("n_fft 400 = win (DFT on the f32 matrix cores)", dict(n_fft=400), 4096),
@@ -39,5 +42,5 @@ for name, kw, b in CASES:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     sec = b * pre.segment_samples / pre.sample_rate
-    print(f"{name:55s} B {b:5d}  {tuple(out.shape[1:])}  {ms:8.3f} ms  {b / ms / 1e3:7.2f} M clips/s  "
+    print(f"{name:55s} [{pre.kernel_path():14s}] B {b:5d}  {tuple(out.shape[1:])}  {ms:8.3f} ms  {b / ms / 1e3:7.2f} M clips/s  "
           f"{sec / ms * 1e3 / 3600:9.1f} audio-hours/s", flush=True)
