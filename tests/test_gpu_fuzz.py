@@ -260,3 +260,47 @@ def test_fullband_featuriser_random_filterbanks_and_flags():
         assert mel < 1e-4 and rel < 1e-4 and cerr < 2e-4, (case, g, flags, normalize, mel, rel, cerr)
     print(f"full-band fuzz: {paths}")
     assert paths["tuned_fullband"] >= 30
+
+
+def test_runtime_geometry_featuriser_random_stft_geometries():
+    """50 seeded random STFT geometries at n_fft = 512 -- sample rate, hop (1..256), window (1..512), segment length (so that the
+    frame count stays <= 128), filterbank and flags -- against the CPU oracle; each must land on the one-launch kernel with the
+    run-time geometry unless the case hits one of its stated limits (PCEN beyond 104 frames; MFCC + delta buffers beyond 16 640 B),
+    which the test computes itself."""
+    from test_oracle_featurizer import geometry_clip
+    rng = np.random.default_rng(606)
+    paths = {"tuned_geometry": 0, "generic": 0, "tuned_fullband": 0, "tuned": 0}
+    for case in range(50):
+        sr = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000]))
+        hop = int(rng.choice([rng.integers(3, 257), 64, 128, 160, 200, 220, 256]))
+        win = int(rng.choice([rng.integers(1, 513), 256, 400, 441, 512]))
+        T = int(rng.integers(max(2, 257 // hop + 2), 129))
+        n = (T - 1) * hop + int(rng.integers(0, hop))
+        if n <= 256:
+            continue
+        n_mels = int(rng.choice([2, 8, 20, 40, 64, 64, 64, 80, 96]))
+        n_mfcc = int(rng.integers(1, min(n_mels, 20) + 1))
+        f_min = float(rng.choice([0.0, 20.0, 100.0, 300.0]))
+        f_max = float(rng.choice([0.25, 0.4, 0.5]) * sr)
+        flags = dict(use_pre_emphasis=bool(rng.integers(2)), use_delta_delta=bool(rng.integers(2)),
+                     use_pcen=bool(rng.integers(3) == 0) and n_mels == 64, use_mfcc=bool(rng.integers(4) > 0),
+                     use_spectral_contrast=False)
+        g = dict(sample_rate=sr, n_mels=n_mels, n_fft=512, hop_length=hop, win_length=win, f_min=f_min, f_max=f_max, n_mfcc=n_mfcc)
+        pre = cda.AudioPreprocessor(device="cuda", segment_duration=(n + 0.5) / sr, **g, **flags)
+        assert pre.segment_samples == n and pre._frames(n) == T, (case, g, n, T)
+        shipped = (sr, hop, win, n) == (16000, 160, 400, 16000)
+        limits = (flags["use_pcen"] and T > 104) or (flags["use_mfcc"] and 2 * n_mfcc * T * 4 > 16640) or \
+            n_mels * T * 4 > 48 * 1024
+        if not shipped and not limits:
+            assert pre.kernel_path() == "tuned_geometry", (case, g, flags, n, T)
+        paths[pre.kernel_path()] += 1
+        w = torch.from_numpy(np.stack([geometry_clip(case + s, n) for s in range(4)]))
+        normalize = bool(rng.integers(2))
+        f = pre.featurize_batch(w.cuda(), normalize=normalize).cpu()
+        ref = ofeat.extract_features_batch(w, normalize_first=normalize, **ofeat.geometry_kwargs(**g), **flags)
+        assert f.shape == ref.shape == (4, pre.get_num_features(), T), (case, g, flags)
+        mel = (f[:, :n_mels] - ref[:, :n_mels]).abs().max().item()
+        rel = ((f[:, n_mels:] - ref[:, n_mels:]).abs() / ref[:, n_mels:].abs().clamp(min=1.0)).max().item() if f.shape[1] > n_mels else 0.0
+        assert mel < 1e-4 and rel < 2e-4, (case, g, flags, n, T, normalize, pre.kernel_path(), mel, rel)
+    print(f"run-time geometry fuzz: {paths}")
+    assert paths["tuned_geometry"] >= 30
