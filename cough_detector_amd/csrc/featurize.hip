@@ -138,7 +138,7 @@ static_assert(ST_X3_OFF % 16 == 0 && ST_IMG % 4 == 0 && ST_X3_OFF >= size_t(NMF)
 struct FullBank {
     int n_mels, n_mfcc, n_taps;
     int maxw[2];             // widest band of bands 0..63 / 64..127 (taps)
-    int n_frames, n_samples, hop;   // GEO instantiations: frames per clip (<= 128), samples per clip, hop length
+    int n_frames, n_samples, hop;   // GEO instantiations: frames per clip, samples per clip, hop length
     int cph, cph_pad, cw;    // MFCCs of the first thread half (ceil(n_mfcc / 2)); table rows per half (whole chunks); chunk width 4..7
     const int *lo, *hi, *off;   // [n_mels] first bin, end bin, offset of the band's taps in w
     const float* w;          // CSR taps, times 1/4 (the spectrum is formed as 2X)
@@ -175,7 +175,8 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps, int n_frames = NFRAMES) 
 // wait in 26 registers from the PCEN branch to the image build, which costs the shipped instantiation 1.3 % when it is a run-time
 // choice (same-box A/B, profiles/r05_bench_flags.txt).
 // GEO (with FULL, no stem): run-time STFT geometry at n_fft = 512 -- any hop <= 256, window <= 512 (all 16 sample pairs of a
-// lane are live), segment length with up to 128 frames, i.e. other sample rates / window durations on the one-launch kernel
+// lane are live), segment length (the dB buffer of n_mels x frames must fit the LDS of two workgroups per CU: 201 frames of 64 bands), i.e. other
+// sample rates / window durations on the one-launch kernel
 // instead of the generic chain.  Samples arrive as 4-byte loads (no alignment contract), two workgroups per CU.
 template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false, bool PCS = false, bool GEO = false>
 __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
@@ -613,8 +614,10 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
     K1_MARK("PHASE P2 DCT 13x64");
     // DCT: thread = (frame t, coefficient half); coefficients are wave-uniform -> scalar loads
     float* mf = xs;              // [13][101] z-scored MFCC
-    float* dl = mf + nmf;        // delta (needed in LDS only for delta-delta)
-    const int tt = tid & 127;
+    // delta (needed in LDS only for delta-delta); GEO: over the dB buffer, which is dead after the DCT -- the scratch then only has
+    // to hold the MFCC rows (n_mfcc x frames x 4 <= 16 640 B: 20 MFCCs of 208 frames)
+    float* dl = GEO ? melbuf : mf + nmf;
+    const int tt0 = tid & 127;
     const int chalf = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: c 0..6; waves 2,3: c 7..12
     if constexpr (FULL) {
         // run-time n_mels / n_mfcc: the half's coefficients in chunks of fbk.cw (the table is [half][cph_pad][n_mels] with zero rows
@@ -623,6 +626,8 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
         const int cph = fbk.cph, nch = chalf ? nmfcc - cph : cph, cbase = chalf * cph;
         auto dct_chunks = [&](auto cw_tag) {
             constexpr int CW = decltype(cw_tag)::value;   // coefficients per chunk
+            // GEO: more than 128 frames take further rounds of (frame, coefficient half) threads (workgroup-uniform trip count)
+            for (int tt = tt0; tt < (GEO ? ((NF + 127) & ~127) : 128); tt += 128)
             for (int cq = 0; cq < nch; cq += CW) {
                 float acc[CW];
 #pragma unroll
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
         K1_STAMP(5);   // DCT + mean + std done
         for (int i = tid; i < nmf; i += THREADS) mf[i] = (mf[i] - mean) * rdenom;
     } else {
-        const int c0 = chalf * 7, nc = chalf ? 6 : 7;
+        const int c0 = chalf * 7, nc = chalf ? 6 : 7, tt = tt0;
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tt < NFRAMES) {
             const float* drow = &tb->dct_t[c0][0];
@@ -1026,7 +1031,7 @@ struct cough_featurizer {
     int n_cus;           // compute units of the device the featuriser was created on
     int kind;            // the one-launch kernel that serves the constructor's segment length: 0 none (generic chain), 1 the
                          // shipped sparse-filterbank instantiations, 2 the full-band ones (any filterbank, run-time n_mels / n_mfcc),
-                         // 3 the full-band ones with a run-time STFT geometry (n_fft 512, hop <= 256, <= 128 frames)
+                         // 3 the full-band ones with a run-time STFT geometry (n_fft 512, hop <= 256)
     char* d_full;        // kind 2: CSR filterbank + DCT rows (one blob)
     cough::FullBank full;
     size_t full_lds;     // kind 2: dynamic LDS of a workgroup
@@ -1060,12 +1065,12 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     std::vector<float> f_taps, f_dct;
     FullBank fb{};
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
-    // lengths of up to 128 frames; no contrast rows (their STFT passes are built for the shipped geometry)
+    // lengths whose dB buffer fits (64 bands: up to 222 frames); no contrast rows (their STFT passes are built for the shipped geometry)
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
     const bool geo_ok = !stft_ok && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
-                        cfg->hop_length <= NFFT / 2 && cfg->segment_samples > NFFT / 2 && geo_frames <= 128 &&
+                        cfg->hop_length <= NFFT / 2 && cfg->segment_samples > NFFT / 2 && geo_frames <= 1024 &&
                         !cfg->use_spectral_contrast && (!cfg->use_pcen || geo_frames <= 104) &&
-                        (!cfg->use_mfcc || 2 * cfg->n_mfcc * geo_frames * 4 <= int(LDS_XCH_FULL));
+                        (!cfg->use_mfcc || size_t(cfg->n_mfcc) * geo_frames * 4 <= LDS_XCH_FULL);
     bool full = false;
     if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
         (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= FULL_MAX_MFCC && cfg->n_mfcc <= cfg->n_mels)) &&

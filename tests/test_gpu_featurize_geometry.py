@@ -4,8 +4,9 @@ CPU oracle.
 ``AudioPreprocessor(sample_rate=..., hop_length=..., win_length=..., segment_duration=...)`` at n_fft = 512
 (``/root/reference/src/preprocessing.py:32-51, 94-136``; ``RealtimePreprocessor(window_duration=...)`` :559-580) used to leave
 the one-launch kernel for the generic kernel chain as soon as the hop, the window or the segment length differed from the shipped
-ones.  The GEO instantiations take hop (<= 256), window (<= 512), segment length (<= 128 frames) and the filterbank at run time;
-contrast rows and longer segments stay on the generic chain."""
+ones.  The GEO instantiations take hop (<= 256), window (<= 512), segment length (while the n_mels x frames dB buffer fits the LDS
+of two workgroups per CU: 2 s windows of 64 bands) and the filterbank at run time; contrast rows and longer segments stay on the
+generic chain."""
 import numpy as np
 import pytest
 import torch
@@ -32,6 +33,11 @@ GEO = {      # name -> (geometry overrides, segment seconds)
     "mel80_mfcc20_hop200": (dict(n_mels=80, n_mfcc=20, f_max=8000.0, hop_length=200), 1.0),
     "mel100_127_frames": (dict(n_mels=100, n_mfcc=16, f_min=0.0, f_max=8000.0, hop_length=126, win_length=512), 1.0),
     "mel2_128_frames": (dict(n_mels=2, n_mfcc=2, f_max=8000.0, hop_length=125, win_length=250), 0.9925),
+    "hop100_161_frames": (dict(hop_length=100), 1.0),
+    "two_seconds_201_frames": (dict(), 2.0),
+    "two_seconds_fmax8k_20mfcc": (dict(f_max=8000.0, n_mfcc=20), 2.0),
+    "five_seconds_20mel_8mfcc_501_frames": (dict(n_mels=20, n_mfcc=8), 5.0),
+    "hop31_130_frames": (dict(hop_length=31, win_length=100), 0.25),
 }
 
 
@@ -55,7 +61,7 @@ def test_runtime_geometry_against_oracle(name):
     assert pre.kernel_path() == "tuned_geometry"
     n, nm = pre.segment_samples, g["n_mels"]
     T = 1 + n // g["hop_length"]
-    assert n > 256 and T <= 128
+    assert n > 256
     w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(12)]))
     w[7] = 0.0                                                       # digital silence: amin clamp, no NaN
     w[8] = 0.25                                                      # DC: only the reflect padding and the window shape it
@@ -85,7 +91,8 @@ def test_runtime_geometry_against_oracle(name):
 @pytest.mark.parametrize("flags", [dict(use_pre_emphasis=True), dict(use_delta_delta=True), dict(use_pcen=True), dict(use_mfcc=False),
                                    dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)],
                          ids=["preemph", "dd", "pcen", "no_mfcc", "preemph_dd_pcen"])
-@pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel"])
+@pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel",
+                                  "two_seconds_201_frames"])
 def test_runtime_geometry_flags(name, flags):
     pre, g = _make(name, **flags)
     kw = {**SHIPPED, **flags}
@@ -107,13 +114,13 @@ def test_what_stays_on_the_generic_chain():
     def path(seconds=1.0, **kw):
         return cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **{**BASE, **SHIPPED, **kw}).kernel_path()
     assert path(hop_length=257) == "generic"                                       # frames would not overlap the packed pairs
-    assert path(hop_length=100) == "generic" and path(2.0) == "generic"            # 161 / 201 frames
+    assert path(5.0) == "generic" and path(2.0, n_mels=80, f_max=8000.0) == "generic"            # 64 x 501 / 80 x 201 dB values
+    assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "generic"
     assert path(hop_length=200, n_mels=63) == "generic" and path(hop_length=200, n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
     assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
     assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS
-    assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "generic"                 # 2 x 20 x 127 MFCC cells
-    assert path(hop_length=126, win_length=512, n_mfcc=16, f_max=8000.0) == "tuned_geometry"
+    assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "tuned_geometry"
 
 
 def test_runtime_geometry_engine_windows(tmp_path):
