@@ -12,6 +12,71 @@
 
 namespace cough {
 
+// `col`: the band's first bin of this frame, bin k at col[k * pitch].  Sums of the CAP-limited largest / smallest values of one frame's band, i.e. of the reference's sorted slices
+// `sorted_band[top_idx:]` / `sorted_band[:bot_idx]` (:279-290) without sorting: the band streams past once while the frame keeps
+// its k largest and k smallest values so far in registers (an insertion network of max / min pairs, 4 CAP operations per value;
+// the rank count below, kept for the bands of more than 128 bins of n_fft = 2048, costs 2 nb per value).  Equal values give the
+// same sums whatever their order, so torch.sort's tie rule is immaterial; max / min drop a NaN, so non-finite powers are
+// tracked in `chk` (v * 0) and poison the result as the reference's NaN-last sort + mean would.
+template <int CAP>
+__device__ __forceinline__ void select_sums(const float* __restrict__ col, int pitch, int nb, int ktop, int kbot, float scale,
+                                            float& top, float& bot, float& chk) {
+    float hi[CAP], lo[CAP];
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) {
+        hi[i] = -INFINITY;
+        lo[i] = INFINITY;
+    }
+#pragma unroll 4
+    for (int k = 0; k < nb; ++k) {
+        const float v = col[(long long)k * pitch] * scale;
+        chk = fmaf(v, 0.f, chk);
+        float x = v, y = v;
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {   // hi: descending
+            const float m = fmaxf(hi[i], x);
+            x = fminf(hi[i], x);
+            hi[i] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {   // lo: ascending
+            const float m = fminf(lo[i], y);
+            y = fmaxf(lo[i], y);
+            lo[i] = m;
+        }
+    }
+    top = 0.f;
+    bot = 0.f;
+#pragma unroll
+    for (int i = CAP - 1; i >= 0; --i)   // ascending, as the sorted slice is summed
+        if (i < ktop) top += hi[i];
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+        if (i < kbot) bot += lo[i];
+}
+
+// The slice sizes of a band of nb bins (python int(n_bins * 0.8) / int(n_bins * 0.2), each at least 1, :279-284) and the selection
+// network that holds the larger of them; nb <= 128 (at most 26 values per slice).
+__device__ __forceinline__ void contrast_select(const float* __restrict__ col, int pitch, int nb, float scale, float& peaks,
+                                                float& valleys, float& chk) {
+    int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);
+    if (top_idx < 1) top_idx = 1;
+    if (bot_idx < 1) bot_idx = 1;
+    const int ktop = nb - top_idx, kbot = bot_idx < nb ? bot_idx : nb, cap = ktop > kbot ? ktop : kbot;
+    float top, bot;
+    if (cap <= 1) select_sums<1>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 2) select_sums<2>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 3) select_sums<3>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 4) select_sums<4>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 6) select_sums<6>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 8) select_sums<8>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 13) select_sums<13>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 18) select_sums<18>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else select_sums<26>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    peaks = top / float(ktop);   // 0 / 0 = NaN when the top slice is empty (one-bin band), as mean() of an empty tensor
+    valleys = bot / float(kbot);
+}
+
 __device__ __forceinline__ int rank_le4(const float4 u, const float v) {
     return int(u.x <= v) + int(u.y <= v) + int(u.z <= v) + int(u.w <= v);
 }

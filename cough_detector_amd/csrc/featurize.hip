@@ -256,6 +256,11 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
     // Frame samples are fetched one group AHEAD of their use (28 VGPRs): the HBM/L2 latency of a
     // group's 14 eight-byte loads hides behind the ~600 VALU instructions of the previous group, and every
     // byte of the clip is requested from HBM once.
+    // GEO: the four frames of group g lie inside the clip with their whole 512-sample spans (wave-uniform)
+    auto geo_plain = [&](int g) {
+        return HP * (FPW * g) - PADL >= 0 && FPW * g + FPW - 1 < NF && HP * (FPW * g + FPW - 1) - PADL + NFFT <= NSMP;
+    };
+    [[maybe_unused]] float raw_left = 0.f;   // GEO with pre-emphasis: the sample in front of the frame's first one (0 at the clip's start)
     auto load_group = [&](int g, float2 (&raw)[16]) {
         const int t_raw = FPW * g + fsub;
         const int t = t_raw < NF ? t_raw : NF - 1;             // idle sub-frames redo the last frame
@@ -263,10 +268,10 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
         if constexpr (GEO) {
             // frames whose whole 512-sample span lies inside the clip load directly, the others by reflected index (torch.stft
             // center / reflect); 4-byte loads: hop and row stride are arbitrary
-            const bool plain = HP * (FPW * g) - PADL >= 0 && FPW * g + FPW - 1 < NF && HP * (FPW * g + FPW - 1) - PADL + NFFT <= NSMP;
-            if (plain) {   // wave-uniform
+            if (geo_plain(g)) {   // wave-uniform
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) raw[n1] = make_float2(x[s0 + 32 * n1], x[s0 + 32 * n1 + 1]);
+                if constexpr (PRE_EMPH) raw_left = s0 - 2 * j > 0 ? x[s0 - 2 * j - 1] : 0.f;
             } else {
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
@@ -329,12 +334,13 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
             if constexpr (PRE_EMPH) {
                 // y[n] = x[n] - coef*x[n-1], y[0] = x[0] (preprocessing.py:235-238), applied before the reflect padding as the
                 // reference does; no FMA contraction (mul_rn, __fsub_rn).  The peak is of x, not of the emphasised signal.
-                if (!GEO && FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN) {   // wave-uniform: frames inside the clip
+                if (GEO ? geo_plain(g) : (FPW * g >= FIRST_PLAIN && FPW * g + FPW - 1 <= LAST_PLAIN)) {   // wave-uniform: frames inside the clip
                     // x[i0 - 1] is the second sample of the lane to the left (row_ror:1); lane 0 takes lane 15's pair of the
-                    // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does)
-                    float carry = 0.f;
+                    // previous n1 (n1 = 1: a zero tap of the padded window, any finite value does; GEO: every tap is live and the
+                    // sample in front of the frame arrives with the group's loads)
+                    float carry = GEO ? raw_left : 0.f;
 #pragma unroll
-                    for (int n1 = 1; n1 < 15; ++n1) {
+                    for (int n1 = N1A; n1 < N1B; ++n1) {
                         const float rot = dpp_mov<0x121>(raw[n1].y);
                         const float left = j == 0 ? carry : rot;
                         carry = rot;
@@ -551,6 +557,47 @@ __global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
     // buffer is still needed for the MFCC branch in between)
     [[maybe_unused]] float pcv[PCS ? 26 : 1];
     K1_MARK("SKIP PCEN branch (off in the shipped configuration)");
+    if (GEO && pcen) {
+        // Run-time frame count (<= 208): thread = (band, quarter of the frames) walks its quarter in up to two chunks of 26 frames
+        // -- the body of the fixed-geometry branch below -- and keeps the values in registers (two workgroups per CU: 256 VGPRs)
+        // until the clip's minimum and maximum are known.
+        const int m = tid >> 2, quarter = (NF + 3) >> 2;
+        const int q0 = (tid & 3) * quarter, q1 = q0 + quarter < NF ? q0 + quarter : NF;
+        float lmin = INFINITY, lmax = -INFINITY;
+        float pv[2][26];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t0 = q0 + 26 * c;
+            if (c == 0 || quarter > 26) {   // workgroup-uniform
+                float p[36], s2[35];
+#pragma unroll
+                for (int k = 0; k < 36; ++k) {
+                    const int u = t0 - 5 + k;
+                    p[k] = (u >= 0 && u < NF) ? exp2f((melbuf[m * NF + u] - shift) * 0.33219280948873623f) : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 35; ++k) s2[k] = p[k] + p[k + 1];
+#pragma unroll
+                for (int k = 0; k < 26; ++k) {
+                    const float sm = ((s2[k] + s2[k + 2]) + (s2[k + 4] + s2[k + 6])) + s2[k + 8];
+                    const float gain = __builtin_amdgcn_exp2f(-0.98f * __builtin_amdgcn_logf(1e-6f + sm * 0.1f));
+                    pv[c][k] = __builtin_amdgcn_sqrtf(fmaf(p[k + 5], gain, 2.0f)) - 1.41421356237309515f;
+                    if (t0 + k < q1) {
+                        lmin = fminf(lmin, pv[c][k]);
+                        lmax = fmaxf(lmax, pv[c][k]);
+                    }
+                }
+            }
+        }
+        const float mn = -block_max(-lmin, red, tid), mx = block_max(lmax, red, tid);
+        const float rng = 1.0f / (mx - mn + 1e-8f);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 26; ++k)
+                if (q0 + 26 * c + k < q1) o[m * NF + q0 + 26 * c + k] = (pv[c][k] - mn) * rng;
+        wr_mel = false;
+    } else
     if (pcen) {
         // PCEN branch of extract_mel_spectrogram (preprocessing.py:305-340, :400-404): mel rows =
         // min-max-normalised (mel / (1e-6 + smooth)^0.98 + 2)^0.5 - 2^0.5, smooth = 10-frame moving average
@@ -1065,11 +1112,11 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     std::vector<float> f_taps, f_dct;
     FullBank fb{};
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
-    // lengths whose dB buffer fits (64 bands: up to 222 frames); no contrast rows (their STFT passes are built for the shipped geometry)
+    // lengths whose dB buffer fits (64 bands: up to 222 frames); contrast rows come from the generic chain's kernels behind it
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
     const bool geo_ok = !stft_ok && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
                         cfg->hop_length <= NFFT / 2 && cfg->segment_samples > NFFT / 2 && geo_frames <= 1024 &&
-                        !cfg->use_spectral_contrast && (!cfg->use_pcen || geo_frames <= 104) &&
+                        (!cfg->use_pcen || geo_frames <= 208) &&   // PCEN: a thread keeps its quarter of a band's frames in 52 registers
                         (!cfg->use_mfcc || size_t(cfg->n_mfcc) * geo_frames * 4 <= LDS_XCH_FULL);
     bool full = false;
     if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
@@ -1118,9 +1165,11 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                       "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
         for (int i = 0; i <= cfg->n_contrast_bands; ++i) {
             const int lo = cfg->contrast_edges[i], hi = cfg->contrast_edges[i + 1];
-            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= ((tuned || full) ? 128 : 1024)),
-                          COUGH_EUNSUPPORTED, "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= %d bins "
-                          "inside the spectrum", i, lo, hi, (tuned || full) ? 128 : 1024);
+            COUGH_REQUIRE(lo >= 0 && lo < cfg->n_fft / 2 + 1 && (i == cfg->n_contrast_bands || hi - lo <= 1024),
+                          COUGH_EUNSUPPORTED, "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= 1024 bins "
+                          "inside the spectrum", i, lo, hi);
+            // the contrast kernel behind the persistent STFT passes (shipped geometry) selects out of bands of <= 128 bins
+            if (i < cfg->n_contrast_bands && hi - lo > 128 && stft_ok) tuned = full = false;
         }
     }
     std::vector<FeatTables> host(1);
@@ -1274,7 +1323,9 @@ bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
     if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
-    return f->contrast.n_bands > 0 && n_clips > 0 ? contrast_workspace_bytes(n_clips) : 0;
+    if (f->contrast.n_bands == 0 || n_clips <= 0) return 0;
+    // contrast rows: behind the persistent STFT passes (shipped geometry), else by the generic chain's kernels
+    return f->kind == 3 ? gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips) : contrast_workspace_bytes(n_clips);
 }
 
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
@@ -1304,7 +1355,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const FullBank nofb{};
     // spectral-contrast rows under the fused normalise: the featurise kernel leaves every clip's peak for the contrast path
     float* peak_out = nullptr;
-    if (f->contrast.n_bands > 0 && norm) {
+    if (f->contrast.n_bands > 0 && norm && f->kind != 3) {
         COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
                       "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
         peak_out = contrast_peaks(d_workspace, n_clips);
@@ -1344,6 +1395,9 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         else go(featurize_kernel<false, 0>, none, f->cfg.use_pcen);
     }
     COUGH_HIP_CHECK(hipGetLastError());
+    if (f->contrast.n_bands > 0 && f->kind == 3)   // run-time geometry: the generic chain's STFT + contrast kernels add the rows
+        return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, n_samples, d_feat, f->nfeat, f->nbase, n_clips, norm,
+                             d_workspace, workspace_bytes, stream, /*contrast_rows_only=*/true);
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)
         return launch_contrast(featurizer_stft_view(f), f->contrast, d_wav, wav_stride, d_feat, f->nfeat, f->nbase,
                                n_clips, norm, d_workspace, workspace_bytes, stream);

@@ -604,65 +604,77 @@ __global__ __launch_bounds__(256) void gen_delta_kernel(float* __restrict__ feat
     }
 }
 
-// raw spectral-contrast rows + centroid row of 64 frames of one clip (the joint z-score follows in gen_zscore_kernel).
-// Per band its rows go to LDS, then each frame ranks its bins (rank = number of smaller values, ties by index -- the
-// position torch.sort would give) and sums the values of rank >= top_idx and < bot_idx: the reference's sorted-slice means
-// without sorting; an empty top slice divides 0 by 0 as the mean of an empty tensor does (:272-293).
+// One raw spectral-contrast row (blockIdx.z < n_bands) or the centroid row (blockIdx.z == n_bands) of 64 frames of one clip; the
+// joint z-score follows in gen_zscore_kernel.  Thread = frame.  A band of up to 128 bins (every band of n_fft <= 1024) streams
+// once past the frame's selection network (contrast_rank.h: select_sums, straight from L2, consecutive frames at consecutive
+// addresses, no LDS).  The wider bands of n_fft = 2048 go to LDS (dynamic: 32 KB, requested only when such a band exists) and
+// each frame ranks its bins (rank = number of smaller values, ties by index -- the position torch.sort would give) and sums the
+// values of rank >= top_idx and < bot_idx: the reference's sorted-slice means without sorting; an empty top slice divides 0 by 0
+// as the mean of an empty tensor does (:272-293).
 __global__ __launch_bounds__(64) void gen_contrast_kernel(const float* __restrict__ P, const float* __restrict__ M, int T, int nfreq,
                                                           ContrastCfg cfg, const float* __restrict__ freqs, float nyquist,
                                                           float* __restrict__ feat, int nfeat, int row0) {
-    __shared__ __attribute__((aligned(16))) float4 band4[G_CT_BINS / 4 * G_TT];   // quad-planar, contrast_rank.h
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float4 band4[];   // [G_CT_BINS / 4 * G_TT] quad-planar, contrast_rank.h
+    const int lane = threadIdx.x, i = blockIdx.z;
     const long long clip = blockIdx.y;
     const int t = blockIdx.x * G_TT + lane;
     const float* Pc = P + clip * (long long)nfreq * T;
-    const float* Mc = M + clip * (long long)nfreq * T;
     float* o = feat + (clip * (long long)nfeat + row0) * T;
-    for (int i = 0; i < cfg.n_bands; ++i) {
-        int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
-        if (high <= low) high = low + 1;
-        if (high > nfreq) high = nfreq;
-        const int nb = high - low, nq = (nb + 3) >> 2;
-        int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
-        if (top_idx < 1) top_idx = 1;
-        if (bot_idx < 1) bot_idx = 1;
-        // the band's rows of FT frames at a time in the 32 KB tile: 64 frames for bands of <= 128 bins (every band of
-        // n_fft <= 1024), 32 / 16 / 8 frames for the wider bands of n_fft = 2048
-        const int FT = nb <= G_CT_BINS ? G_TT : nb <= 2 * G_CT_BINS ? G_TT / 2 : nb <= 4 * G_CT_BINS ? G_TT / 4 : G_TT / 8;
-        for (int sub = 0; sub < G_TT / FT; ++sub) {
-            const int ts = blockIdx.x * G_TT + sub * FT + lane;
-            if (blockIdx.x * G_TT + sub * FT >= T) break;   // wave-uniform: nothing left of this tile
-            __syncthreads();
-            if (lane < FT) {
-                const float nan = __builtin_nanf("");
-                for (int q = 0; q < nq; ++q) {
-                    const float* src = Pc + (long long)(low + 4 * q) * T + ts;
-                    float4 u;
-                    u.x = ts < T ? src[0] : 0.f;
-                    u.y = 4 * q + 1 < nb ? (ts < T ? src[T] : 0.f) : nan;
-                    u.z = 4 * q + 2 < nb ? (ts < T ? src[2LL * T] : 0.f) : nan;
-                    u.w = 4 * q + 3 < nb ? (ts < T ? src[3LL * T] : 0.f) : nan;
-                    band4[q * FT + lane] = u;
-                }
+    if (i == cfg.n_bands) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
+        if (t < T) {
+            const float* Mc = M + clip * (long long)nfreq * T;
+            float num = 0.f, den = 0.f;
+            for (int k = 0; k < nfreq; ++k) {
+                const float m = Mc[(long long)k * T + t];
+                num += freqs[k] * m;
+                den += m;
             }
-            __syncthreads();
-            if (lane < FT) {
-                float top, bot;
-                contrast_band_sums(band4, FT, lane, nb, top_idx, bot_idx, top, bot);
-                const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
-                const float valleys = bot / float(bot_idx);
-                if (ts < T) o[(long long)i * T + ts] = log1pf(peaks) - log1pf(valleys);
-            }
+            o[(long long)cfg.n_bands * T + t] = (num / den) / nyquist;
         }
+        return;
     }
-    if (t < T) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
-        float num = 0.f, den = 0.f;
-        for (int k = 0; k < nfreq; ++k) {
-            const float m = Mc[(long long)k * T + t];
-            num += freqs[k] * m;
-            den += m;
+    int low = cfg.edges[i], high = cfg.edges[i + 1];   // :272-278
+    if (high <= low) high = low + 1;
+    if (high > nfreq) high = nfreq;
+    const int nb = high - low;
+    if (nb <= G_CT_BINS) {   // workgroup-uniform
+        if (t < T) {
+            float peaks, valleys, chk = 0.f;
+            contrast_select(Pc + (long long)low * T + t, T, nb, 1.0f, peaks, valleys, chk);
+            o[(long long)i * T + t] = (log1pf(peaks) - log1pf(valleys)) + chk;
         }
-        o[(long long)cfg.n_bands * T + t] = (num / den) / nyquist;
+        return;
+    }
+    const int nq = (nb + 3) >> 2;
+    int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
+    if (top_idx < 1) top_idx = 1;
+    if (bot_idx < 1) bot_idx = 1;
+    // the band's rows of FT frames at a time in the 32 KB tile: 32 / 16 / 8 frames for bands of up to 256 / 512 / 1024 bins
+    const int FT = nb <= 2 * G_CT_BINS ? G_TT / 2 : nb <= 4 * G_CT_BINS ? G_TT / 4 : G_TT / 8;
+    for (int sub = 0; sub < G_TT / FT; ++sub) {
+        const int ts = blockIdx.x * G_TT + sub * FT + lane;
+        if (blockIdx.x * G_TT + sub * FT >= T) break;   // wave-uniform: nothing left of this tile
+        __syncthreads();
+        if (lane < FT) {
+            const float nan = __builtin_nanf("");
+            for (int q = 0; q < nq; ++q) {
+                const float* src = Pc + (long long)(low + 4 * q) * T + ts;
+                float4 u;
+                u.x = ts < T ? src[0] : 0.f;
+                u.y = 4 * q + 1 < nb ? (ts < T ? src[T] : 0.f) : nan;
+                u.z = 4 * q + 2 < nb ? (ts < T ? src[2LL * T] : 0.f) : nan;
+                u.w = 4 * q + 3 < nb ? (ts < T ? src[3LL * T] : 0.f) : nan;
+                band4[q * FT + lane] = u;
+            }
+        }
+        __syncthreads();
+        if (lane < FT) {
+            float top, bot;
+            contrast_band_sums(band4, FT, lane, nb, top_idx, bot_idx, top, bot);
+            const float peaks = top / float(nb - top_idx);   // 0 / 0 = NaN when the top slice is empty
+            const float valleys = bot / float(bot_idx);
+            if (ts < T) o[(long long)i * T + ts] = log1pf(peaks) - log1pf(valleys);
+        }
     }
 }
 
@@ -961,7 +973,7 @@ int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, 
 
 int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
                   long long wav_stride, int n_samples, float* d_feat, int nfeat, int nbase, int n_clips, int normalize,
-                  void* d_workspace, size_t workspace_bytes, hipStream_t stream) {
+                  void* d_workspace, size_t workspace_bytes, hipStream_t stream, bool contrast_rows_only) {
     const int N = n_samples > 0 ? n_samples : g->N, T = gen_frames(g, N);
     COUGH_REQUIRE(N > g->nfft / 2, COUGH_EINVAL, "cough_featurize: %d samples: the reflect padding of torch.stft(center=True) needs "
                   "more than n_fft / 2 = %d", N, g->nfft / 2);
@@ -988,6 +1000,7 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         const dim3 gt((T + G_TT - 1) / G_TT, nc);
         // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
         const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, g->n_taps}, none{0, nullptr, nullptr, nullptr, nullptr, 0};
+        if (!contrast_rows_only) {   // (else the one-launch kernel has written rows [0, nbase): featurize.hip, run-time geometry)
         gen_launch_stft<false, true>(g, N, T, w, wav_stride, nc, g->win, pk, cfg.use_pre_emphasis, cfg.pre_emphasis_coef, mel, gm, stream);
         hipLaunchKernelGGL(gen_dbstat_kernel, dim3(nc), dim3(256), 0, stream, mel, T, n_mels, cfg.use_pcen, stat);
         hipLaunchKernelGGL(gen_rows_kernel, gt, dim3(256), size_t(n_mels) * G_TT * sizeof(float), stream, mel, T, n_mels, cfg.use_mfcc ? n_mfcc : 0, cfg.use_pcen, stat,
@@ -997,11 +1010,15 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
             hipLaunchKernelGGL(gen_delta_kernel, dim3((n_mfcc * T + 255) / 256, nc), dim3(256), 0, stream, feat, nfeat, T, n_mels,
                                n_mfcc, cfg.use_delta_delta);
         }
+        }
         if (want_contrast) {
             // from the un-emphasised (normalised) signal (:476-478)
             gen_launch_stft<false, false>(g, N, T, w, wav_stride, nc, g->win, pk, 0, 0.f, P, none, stream);
             gen_launch_stft<true, false>(g, N, T, w, wav_stride, nc, g->win_full, pk, 0, 0.f, M, none, stream);
-            hipLaunchKernelGGL(gen_contrast_kernel, gt, dim3(64), 0, stream, P, M, T, g->nfreq, contrast, g->freqs,
+            bool wide = false;   // a band of more than 128 bins (n_fft = 2048 only) ranks its bins out of LDS
+            for (int i = 0; i < contrast.n_bands; ++i) wide |= contrast.edges[i + 1] - contrast.edges[i] > G_CT_BINS;
+            hipLaunchKernelGGL(gen_contrast_kernel, dim3(gt.x, gt.y, contrast.n_bands + 1), dim3(64),
+                               wide ? size_t(G_CT_BINS / 4 * G_TT) * sizeof(float4) : 0, stream, P, M, T, g->nfreq, contrast, g->freqs,
                                float(g->sample_rate) / 2.0f, feat, nfeat, nbase);
             hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
         }

@@ -62,7 +62,7 @@ int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, 
                     hipStream_t stream);
 int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const ContrastCfg& contrast, const float* d_wav,
                   long long wav_stride, int n_samples, float* d_feat, int nfeat, int nbase, int n_clips, int normalize,
-                  void* d_workspace, size_t workspace_bytes, hipStream_t stream);
+                  void* d_workspace, size_t workspace_bytes, hipStream_t stream, bool contrast_rows_only = false);
 const GenFeat* featurizer_generic(const cough_featurizer* f);   // every featuriser has the generic chain's tables
 bool featurizer_tuned(const cough_featurizer* f, int n_samples = 0);   // the one-launch kernel serves waveforms of this length
 bool featurizer_shipped_stft(const cough_featurizer* f, int n_samples = 0);   // ... at the shipped STFT geometry (persistent STFT kernel)

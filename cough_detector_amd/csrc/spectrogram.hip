@@ -391,49 +391,6 @@ __device__ __forceinline__ float ct_block_sum(float v, float* red, int tid) {
     return red[0] + red[1];
 }
 
-// Sums of the CAP-limited largest / smallest values of one frame's band, i.e. of the reference's sorted slices
-// `sorted_band[top_idx:]` / `sorted_band[:bot_idx]` (:279-290) without sorting: the band streams past once while the frame keeps
-// its k largest and k smallest values so far in registers (an insertion network of max / min pairs, 4 CAP operations per value;
-// the rank count it replaces -- contrast_rank.h, still used by the generic chain -- costs 2 nb per value).  Equal values give the
-// same sums whatever their order, so torch.sort's tie rule is immaterial; max / min drop a NaN, so non-finite powers are
-// tracked in `chk` (v * 0) and poison the result as the reference's NaN-last sort + mean would.
-template <int CAP>
-__device__ __forceinline__ void select_sums(const float* __restrict__ col, int nb, int ktop, int kbot, float scale, float& top,
-                                            float& bot, float& chk) {
-    float hi[CAP], lo[CAP];
-#pragma unroll
-    for (int i = 0; i < CAP; ++i) {
-        hi[i] = -INFINITY;
-        lo[i] = INFINITY;
-    }
-#pragma unroll 4
-    for (int k = 0; k < nb; ++k) {
-        const float v = col[k * NFRAMES] * scale;
-        chk = fmaf(v, 0.f, chk);
-        float x = v, y = v;
-#pragma unroll
-        for (int i = 0; i < CAP; ++i) {   // hi: descending
-            const float m = fmaxf(hi[i], x);
-            x = fminf(hi[i], x);
-            hi[i] = m;
-        }
-#pragma unroll
-        for (int i = 0; i < CAP; ++i) {   // lo: ascending
-            const float m = fminf(lo[i], y);
-            y = fmaxf(lo[i], y);
-            lo[i] = m;
-        }
-    }
-    top = 0.f;
-    bot = 0.f;
-#pragma unroll
-    for (int i = CAP - 1; i >= 0; --i)   // ascending, as the sorted slice is summed
-        if (i < ktop) top += hi[i];
-#pragma unroll
-    for (int i = 0; i < CAP; ++i)
-        if (i < kbot) bot += lo[i];
-}
-
 // One 128-thread workgroup per clip, thread = frame: band contrasts out of the power rows the STFT kernel left in the workspace
 // (read once, straight from L2: consecutive frames are consecutive addresses), the centroid row from the centroid-mode STFT
 // pass, the joint z-score (:300), rows stored behind the MFCC block.
@@ -461,24 +418,9 @@ __global__ __launch_bounds__(CT_THREADS) void contrast_kernel(const float* __res
         if (high <= low) high = low + 1;
         if (high > NFREQ) high = NFREQ;
         const int nb = high - low;
-        int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);   // python int(n_bins * 0.8)
-        if (top_idx < 1) top_idx = 1;
-        if (bot_idx < 1) bot_idx = 1;
-        const int ktop = nb - top_idx, kbot = bot_idx < nb ? bot_idx : nb, cap = ktop > kbot ? ktop : kbot;
         if (tid < NFRAMES) {
-            const float* col = P + low * NFRAMES + tid;
-            float top, bot, chk = 0.f;
-            if (cap <= 1) select_sums<1>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 2) select_sums<2>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 3) select_sums<3>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 4) select_sums<4>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 6) select_sums<6>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 8) select_sums<8>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 13) select_sums<13>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else if (cap <= 18) select_sums<18>(col, nb, ktop, kbot, scale, top, bot, chk);
-            else select_sums<26>(col, nb, ktop, kbot, scale, top, bot, chk);   // nb <= 128: at most 26 values per slice
-            const float pk = top / float(ktop);   // 0 / 0 = NaN when the top slice is empty (one-bin band), as mean() of an empty tensor
-            const float valleys = bot / float(kbot);
+            float pk, valleys, chk = 0.f;
+            contrast_select(P + low * NFRAMES + tid, NFRAMES, nb, scale, pk, valleys, chk);
             cr[i * NFRAMES + tid] = (log1pf(pk) - log1pf(valleys)) + chk;
         }
     }

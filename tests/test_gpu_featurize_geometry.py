@@ -89,8 +89,12 @@ def test_runtime_geometry_against_oracle(name):
 
 
 @pytest.mark.parametrize("flags", [dict(use_pre_emphasis=True), dict(use_delta_delta=True), dict(use_pcen=True), dict(use_mfcc=False),
-                                   dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True)],
-                         ids=["preemph", "dd", "pcen", "no_mfcc", "preemph_dd_pcen"])
+                                   dict(use_pre_emphasis=True, use_delta_delta=True, use_pcen=True),
+                                   dict(use_spectral_contrast=True, n_contrast_bands=4),
+                                   dict(use_spectral_contrast=True, n_contrast_bands=3, use_pre_emphasis=True, use_delta_delta=True),
+                                   dict(use_spectral_contrast=True, n_contrast_bands=1, use_mfcc=False)],
+                         ids=["preemph", "dd", "pcen", "no_mfcc", "preemph_dd_pcen", "contrast4", "contrast3_preemph_dd",
+                              "contrast1_wide_band_no_mfcc"])
 @pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel",
                                   "two_seconds_201_frames"])
 def test_runtime_geometry_flags(name, flags):
@@ -98,16 +102,20 @@ def test_runtime_geometry_flags(name, flags):
     kw = {**SHIPPED, **flags}
     n, nm = pre.segment_samples, g["n_mels"]
     T = 1 + n // g["hop_length"]
-    # PCEN keeps its values in registers across 104 frames at most and is built for 64 bands: beyond, the generic chain
-    want = "generic" if flags.get("use_pcen") and (T > 104 or nm != 64) else "tuned_geometry"
+    # PCEN is built for 64 bands (thread = band x quarter of the frames): other band counts take the generic chain
+    want = "generic" if flags.get("use_pcen") and nm != 64 else "tuned_geometry"
     assert pre.kernel_path() == want
     w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(6)]))
     got = pre.featurize_batch(w.cuda(), normalize=True)
     ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g), **kw)
     assert got.shape == ref.shape == (6, pre.get_num_features(), T)
-    mel, rel = _errors(got, ref, nm)
-    print(f"{name} {flags} [{want}]: mel abs {mel:.2e}, rest rel {rel:.2e}")
-    assert mel < FEAT_TOL and rel < FEAT_TOL
+    nbase = got.shape[1] - (flags["n_contrast_bands"] + 1 if flags.get("use_spectral_contrast") else 0)
+    mel, rel = _errors(got[:, :nbase], ref[:, :nbase], nm)
+    cerr = (got[:, nbase:].cpu() - ref[:, nbase:]).abs().max().item() if nbase < got.shape[1] else 0.0     # unit-variance rows
+    print(f"{name} {flags} [{want}]: mel abs {mel:.2e}, rest rel {rel:.2e}, contrast rows abs {cerr:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL and cerr < 2e-4
+    if nbase < got.shape[1]:       # batch invariance with the contrast rows' sub-batches and scratch
+        assert torch.equal(pre.featurize_batch(w[2:3].cuda(), normalize=True)[0], got[2])
 
 
 def test_what_stays_on_the_generic_chain():
@@ -116,7 +124,7 @@ def test_what_stays_on_the_generic_chain():
     assert path(hop_length=257) == "generic"                                       # frames would not overlap the packed pairs
     assert path(5.0) == "generic" and path(2.0, n_mels=80, f_max=8000.0) == "generic"            # 64 x 501 / 80 x 201 dB values
     assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
-    assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "generic"
+    assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "tuned_geometry"   # rows [0, nbase) in one launch
     assert path(hop_length=200, n_mels=63) == "generic" and path(hop_length=200, n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
     assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
     assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS

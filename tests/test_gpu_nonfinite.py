@@ -162,7 +162,7 @@ def test_engine_keeps_a_nan_in_its_smoothing_history_like_the_reference(tmp_path
     assert events == ref_events and any(events)
 
 
-@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_hop300"])
+@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_hop300", "tuned_geometry_hop100_161_frames"])
 def test_contrast_rows_of_extreme_peak_clips_under_normalize(geo):
     """The spectral-contrast rows come from a second STFT of the un-emphasised signal; with `normalize` the reference has divided
     by the peak first (:199-212, :476-478), so a denormal or huge clip gives the rows of the same clip at unit peak.  The tuned

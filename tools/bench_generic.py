@@ -24,10 +24,17 @@ CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
          ("n_fft 1024, win 400 (radix-4 Stockham kernel)", dict(n_fft=1024), 4096),
          ("n_fft 256, win 256, hop 128", dict(n_fft=256, win_length=256, hop_length=128), 4096),
          ("n_fft 400 = win (DFT on the f32 matrix cores)", dict(n_fft=400), 4096),
+         ("2 s + pre-emphasis", dict(segment_duration=2.0, use_pre_emphasis=True), 2048),
+         ("2 s + PCEN", dict(segment_duration=2.0, use_pcen=True), 2048),
+         ("2 s + delta-delta", dict(segment_duration=2.0, use_delta_delta=True), 2048),
+         ("0.5 s + PCEN", dict(segment_duration=0.5, use_pcen=True), 8192),
          ("2 s, all constructor defaults but 4 contrast bands", dict(segment_duration=2.0, use_pcen=True, use_pre_emphasis=True,
                                                                     use_delta_delta=True, use_spectral_contrast=True,
                                                                     n_contrast_bands=4), 2048)]
+only = sys.argv[1] if len(sys.argv) > 1 else ""      # substring filter, e.g. for a rocprofv3 run of one case
 for name, kw, b in CASES:
+    if only not in name:
+        continue
     flags = {**SHIPPED, **{k: v for k, v in kw.items() if k.startswith("use_") or k == "n_contrast_bands"}}
     geom = {k: v for k, v in kw.items() if k not in flags}
     pre = cda.AudioPreprocessor(device="cuda", **geom, **flags)
