@@ -98,12 +98,22 @@ struct GenMel {
     const float* w;
     int n_taps;   // length of w
 };
-template <bool MAG, bool MEL>
+// TAIL (n_fft = 512 only; `out` is then the feature image and the spectrogram never leaves the workgroup): 1 = the raw
+// spectral-contrast rows straight out of the tile of powers (thread = (frame, band): contrast_rank.h's selection networks on LDS
+// columns; bands of <= 128 bins, which every band of 257 bins is); 2 = the spectral-centroid row out of the tile of magnitudes.
+struct GenTail {
+    ContrastCfg cfg;
+    const float* freqs;   // [257] bin frequencies in Hz
+    float nyquist;
+    int nfeat, row0;      // rows of the feature image, first contrast row
+};
+template <bool MAG, bool MEL, int TAIL = 0>
 __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
                                                        const float2* __restrict__ tw512, const float* __restrict__ peaks,
                                                        int pre_emph, float coef, float* __restrict__ out, GenMel mel,
-                                                       long long n_rows /* clips x T */) {
+                                                       long long n_rows /* clips x T */, GenTail tail) {
+    static_assert(TAIL == 0 || (!MEL && MAG == (TAIL == 2)), "contrast rows from powers, the centroid from magnitudes");
     __shared__ float xs[4 * 4 * G_XFRAME];
     __shared__ float otile[G_NFREQ * (G_FPB + 1)];
     __shared__ float2 twl[16 * G_XROW];
@@ -177,7 +187,40 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     }
     if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
     __syncthreads();
-    if constexpr (MEL) {
+    if constexpr (TAIL == 1) {   // raw contrast rows (:272-293): thread = (frame f of the tile, band i)
+        const int f = tid & 15, i = tid >> 4;
+        const long long orow = row0 + f;
+        if (i < tail.cfg.n_bands && orow < n_rows) {
+            const long long oclip = orow / T;
+            int low = tail.cfg.edges[i], high = tail.cfg.edges[i + 1];
+            if (high <= low) high = low + 1;
+            if (high > G_NFREQ) high = G_NFREQ;
+            float pk, valleys, chk = 0.f;
+            contrast_select(otile + low * (G_FPB + 1) + f, G_FPB + 1, high - low, 1.0f, pk, valleys, chk);
+            out[(oclip * tail.nfeat + tail.row0 + i) * T + (orow - oclip * T)] = (log1pf(pk) - log1pf(valleys)) + chk;
+        }
+    } else if constexpr (TAIL == 2) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
+        const int f = tid & 15, grp = tid >> 4;
+        float num = 0.f, den = 0.f;
+        for (int k = grp; k < G_NFREQ; k += 16) {
+            const float m = otile[k * (G_FPB + 1) + f];
+            num = fmaf(tail.freqs[k], m, num);
+            den += m;
+        }
+        float2* part = reinterpret_cast<float2*>(xs);   // [16 bin groups][16 frames]: the transpose scratch is free
+        part[grp * 16 + f] = make_float2(num, den);
+        __syncthreads();
+        const long long orow = row0 + tid;
+        if (tid < 16 && orow < n_rows) {
+            float sn = 0.f, sd = 0.f;
+            for (int q = 0; q < 16; ++q) {
+                sn += part[q * 16 + tid].x;
+                sd += part[q * 16 + tid].y;
+            }
+            const long long oclip = orow / T;
+            out[(oclip * tail.nfeat + tail.row0 + tail.cfg.n_bands) * T + (orow - oclip * T)] = (sn / sd) / tail.nyquist;
+        }
+    } else if constexpr (MEL) {
         // thread = (frame f of the tile, band m mod 16): bins of a band in ascending order.  The CSR filterbank moves into the
         // (now free) transpose scratch first when it fits -- a triangular bank has ~2 taps per bin --, so a tap is an LDS read
         // instead of a dependent global load
@@ -743,7 +786,7 @@ void gen_launch_stft(const GenFeat* g, int N, int T, const float* w, long long w
     if (g->nfft == G_NFFT) {
         const long long n_rows = (long long)nc * T;
         hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_FPB - 1) / G_FPB)), dim3(256), 0, stream, w,
-                           wav_stride, N, g->hop, T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows);
+                           wav_stride, N, g->hop, T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows, GenTail{});
     } else if (g->nfft >= 64 && (g->nfft & (g->nfft - 1)) == 0) {
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, N, g->hop, T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
@@ -929,6 +972,13 @@ int gen_frames(const GenFeat* g, int n_samples) {
 }
 
 namespace {
+// n_fft = 512 with bands of <= 128 bins (every geometric band layout of 257 bins): the contrast and centroid rows come straight out of
+// the STFT workgroups' tiles (gen_stft_kernel TAIL) -- no spectrogram in the workspace
+bool contrast_in_stft(const GenFeat* g, int n_bands, const int* edges) {
+    bool ok = g->nfft == G_NFFT && n_bands >= 1 && n_bands <= 16;
+    for (int i = 0; ok && i < n_bands; ++i) ok = edges[i + 1] - edges[i] <= G_CT_BINS;
+    return ok;
+}
 struct GenCarve {
     int sub;                 // clips per sub-batch
     size_t o_peaks, o_stat, o_P, o_M, o_mel, total;
@@ -953,7 +1003,8 @@ GenCarve gen_carve(const GenFeat* g, bool contrast, int T, int n_clips) {
 }  // namespace
 
 size_t gen_workspace_bytes(const GenFeat* g, const cough_feat_config& cfg, int n_samples, int n_clips) {
-    return n_clips > 0 ? gen_carve(g, cfg.use_spectral_contrast != 0, gen_frames(g, n_samples), n_clips).total : 0;
+    const bool spectrograms = cfg.use_spectral_contrast && !contrast_in_stft(g, cfg.n_contrast_bands, cfg.contrast_edges);
+    return n_clips > 0 ? gen_carve(g, spectrograms, gen_frames(g, n_samples), n_clips).total : 0;
 }
 
 int gen_spectrogram(const GenFeat* g, const float* d_wav, long long wav_stride, int n_samples, float* d_spec, int n_clips, int flags,
@@ -979,7 +1030,8 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
                   "more than n_fft / 2 = %d", N, g->nfft / 2);
     COUGH_REQUIRE(wav_stride >= N, COUGH_EINVAL, "cough_featurize: row stride %lld < %d samples", wav_stride, N);
     const bool want_contrast = contrast.n_bands > 0;
-    const GenCarve c = gen_carve(g, want_contrast, T, n_clips);
+    const bool narrow = want_contrast && contrast_in_stft(g, contrast.n_bands, contrast.edges);
+    const GenCarve c = gen_carve(g, want_contrast && !narrow, T, n_clips);
     COUGH_REQUIRE(d_workspace && workspace_bytes >= c.total, COUGH_EWORKSPACE,
                   "this featuriser geometry runs on the generic kernel chain and needs a workspace of "
                   "cough_featurizer_workspace_bytes() = %zu bytes (cough_featurize_ws)", c.total);
@@ -1013,6 +1065,18 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         }
         if (want_contrast) {
             // from the un-emphasised (normalised) signal (:476-478)
+            if (narrow) {   // n_fft = 512: rows straight out of the STFT workgroups' tiles
+                const long long n_rows = (long long)nc * T;
+                const dim3 gs((unsigned)((n_rows + G_FPB - 1) / G_FPB));
+                const GenTail tail{contrast, g->freqs, float(g->sample_rate) / 2.0f, nfeat, nbase};
+                hipLaunchKernelGGL((gen_stft_kernel<false, false, 1>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, g->win,
+                                   g->tw256, g->tw512, pk, 0, 0.f, feat, none, n_rows, tail);
+                hipLaunchKernelGGL((gen_stft_kernel<true, false, 2>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, g->win_full,
+                                   g->tw256, g->tw512, pk, 0, 0.f, feat, none, n_rows, tail);
+                hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
+                COUGH_HIP_CHECK(hipGetLastError());
+                continue;
+            }
             gen_launch_stft<false, false>(g, N, T, w, wav_stride, nc, g->win, pk, 0, 0.f, P, none, stream);
             gen_launch_stft<true, false>(g, N, T, w, wav_stride, nc, g->win_full, pk, 0, 0.f, M, none, stream);
             bool wide = false;   // a band of more than 128 bins (n_fft = 2048 only) ranks its bins out of LDS
