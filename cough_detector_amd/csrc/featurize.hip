@@ -1096,7 +1096,8 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     // mel bands, up to 20 MFCCs) -- all 257 bins, CSR filterbank in LDS.  Everything else goes to the generic kernel chain
     // (featurize_generic.hip), whose tables every featuriser carries for waveforms of other lengths.
     const int nfreq0 = NFFT / 2 + 1;
-    const bool stft_ok = cfg->sample_rate == 16000 && cfg->n_fft == NFFT && cfg->hop_length == HOP && cfg->win_length == WIN &&
+    // (the sample rate only shapes the filterbank, which arrives as a table: 2 s at 8 kHz or 0.5 s at 32 kHz are the same STFT)
+    const bool stft_ok = cfg->n_fft == NFFT && cfg->hop_length == HOP && cfg->win_length == WIN &&
                          cfg->segment_samples == NS;
     bool tuned = stft_ok && cfg->n_mels == NMEL && cfg->n_mfcc == NMFCC;
     if (tuned) {

@@ -168,3 +168,27 @@ def test_fullband_full_size_batch_properties():
     assert flat.mean(dim=1).abs().max().item() < 1e-4 and (flat.std(dim=1) - 1).abs().max().item() < 1e-4
     pad = torch.nn.functional.pad(mf, (1, 1), mode="replicate")
     assert torch.equal(dl, (pad[:, :, 2:] - pad[:, :, :-2]) / 2)
+
+
+@pytest.mark.parametrize("sr,seconds,over", [(8000, 2.0, dict(f_max=4000.0)), (32000, 0.5, dict(f_max=8000.0, n_mels=80, n_mfcc=20)),
+                                             (8000, 2.0, dict(f_max=1900.0))],
+                         ids=["8kHz_2s", "32kHz_half_second_80mel", "8kHz_2s_narrow_bank"])
+def test_same_stft_at_another_sample_rate(sr, seconds, over):
+    """16 000 samples / hop 160 / window 400 at another sample rate is the shipped STFT with another filterbank (which arrives as a
+    table): the one-launch kernels with the fused stem serve it, contrast + centroid rows included (the centroid is a ratio:
+    sum(f_k |X_k|) / sum(|X_k|) / (sample_rate / 2) does not depend on the rate)."""
+    from test_oracle_featurizer import geometry_clip
+    g = _geo({"sample_rate": sr, **over})
+    flags = {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 3, "use_delta_delta": True}
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **g, **flags)
+    assert pre.segment_samples == 16000 and pre.kernel_path() == ("tuned" if over["f_max"] < sr / 4 else "tuned_fullband")
+    w = torch.from_numpy(np.stack([geometry_clip(s, 16000) for s in range(8)]))
+    got = pre.featurize_batch(w.cuda(), normalize=True).cpu()
+    ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**g), **flags)
+    nm = g["n_mels"]
+    nbase = nm + 3 * g["n_mfcc"]
+    assert got.shape == ref.shape == (8, nbase + 4, 101)
+    mel, rel = _errors(got[:, :nbase], ref[:, :nbase], nm)
+    cerr = (got[:, nbase:] - ref[:, nbase:]).abs().max().item()
+    print(f"{sr} Hz x {seconds} s [{pre.kernel_path()}]: mel abs {mel:.2e}, rest rel {rel:.2e}, contrast rows abs {cerr:.2e}")
+    assert mel < FEAT_TOL and rel < FEAT_TOL and cerr < 2e-4
