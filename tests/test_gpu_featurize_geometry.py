@@ -177,3 +177,31 @@ def test_runtime_geometry_full_size_batch_properties():
     assert flat.mean(dim=1).abs().max().item() < 1e-4 and (flat.std(dim=1) - 1).abs().max().item() < 1e-4
     pad = torch.nn.functional.pad(mf, (1, 1), mode="replicate")
     assert torch.equal(dl, (pad[:, :, 2:] - pad[:, :, :-2]) / 2)
+
+
+def test_pipeline_on_a_runtime_geometry_with_contrast_rows():
+    """CoughPipeline over a run-time-geometry featuriser (0.5 s windows, 3 contrast bands + centroid: a 94 x 51 image): the stem
+    is not fused there and the image size is not one of the split-bf16 instantiations, so the exact-f32 kernels classify it
+    (announced by effective_dtype); logits vs featurise -> oracle classifier."""
+    from oracle import resnet as ores
+    from parity import realistic_state_dict
+    sd = realistic_state_dict(17)
+    flags = {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 3}
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=0.5, **BASE, **flags)
+    assert pre.kernel_path() == "tuned_geometry" and pre.get_num_features() == 94
+    model = cda.create_model("residual", n_mels=94, num_classes=2, in_channels=1, compute_dtype="bf16x3")
+    model.load_state_dict(sd)
+    model.eval()
+    pipe = cda.CoughPipeline(pre, model)
+    w = torch.from_numpy(np.stack([geometry_clip(s, 8000) for s in range(24)]))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        logits, feats = pipe(w.cuda(), normalize=True, return_features=True)
+    assert model.effective_dtype(94, 51) == "fp32" and feats.shape == (24, 94, 51)
+    ref_f = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**BASE), **flags)
+    assert (feats.cpu() - ref_f).abs().max().item() < 2e-4
+    ref_l = ores.forward(ref_f[:, None], sd)
+    err = (logits.cpu() - ref_l).abs().max().item()
+    print(f"pipeline on 94 x 51 images: logits max abs err {err:.2e}")
+    assert err < 1e-3 and torch.equal(logits.cpu().argmax(1), ref_l.argmax(1))
