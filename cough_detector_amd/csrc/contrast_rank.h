@@ -56,7 +56,8 @@ __device__ __forceinline__ void select_sums(const float* __restrict__ col, int p
 }
 
 // The slice sizes of a band of nb bins (python int(n_bins * 0.8) / int(n_bins * 0.2), each at least 1, :279-284) and the selection
-// network that holds the larger of them; nb <= 128 (at most 26 values per slice).
+// network that holds the larger of them; nb <= 128 (at most 26 values per slice), or nb <= 64 with MAXCAP = 13 (fewer registers).
+template <int MAXCAP = 26>
 __device__ __forceinline__ void contrast_select(const float* __restrict__ col, int pitch, int nb, float scale, float& peaks,
                                                 float& valleys, float& chk) {
     int top_idx = (int)((double)nb * 0.8), bot_idx = (int)((double)nb * 0.2);
@@ -70,7 +71,7 @@ __device__ __forceinline__ void contrast_select(const float* __restrict__ col, i
     else if (cap <= 4) select_sums<4>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
     else if (cap <= 6) select_sums<6>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
     else if (cap <= 8) select_sums<8>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
-    else if (cap <= 13) select_sums<13>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
+    else if (cap <= 13 || MAXCAP <= 13) select_sums<13>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
     else if (cap <= 18) select_sums<18>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
     else select_sums<26>(col, pitch, nb, ktop, kbot, scale, top, bot, chk);
     peaks = top / float(ktop);   // 0 / 0 = NaN when the top slice is empty (one-bin band), as mean() of an empty tensor

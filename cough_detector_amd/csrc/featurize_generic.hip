@@ -100,51 +100,80 @@ struct GenMel {
 };
 // TAIL (n_fft = 512 only; `out` is then the feature image and the spectrogram never leaves the workgroup): 1 = the raw
 // spectral-contrast rows straight out of the tile of powers (thread = (frame, band): contrast_rank.h's selection networks on LDS
-// columns; bands of <= 128 bins, which every band of 257 bins is); 2 = the spectral-centroid row out of the tile of magnitudes.
+// columns; bands of <= 64 bins, which the reference's 1 .. 16 geometric bands of 257 bins are); 2 = the spectral-centroid row out of the tile of magnitudes.
 struct GenTail {
     ContrastCfg cfg;
     const float* freqs;   // [257] bin frequencies in Hz
     float nyquist;
     int nfeat, row0;      // rows of the feature image, first contrast row
 };
-template <bool MAG, bool MEL, int TAIL = 0>
-__global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
+// G_CHUNK consecutive 16-frame tiles per workgroup: the next tile's samples are requested (registers) before the current tile's
+// FFTs run, and the window taps stay in registers across the tiles.  PE: pre-emphasis (a template parameter: its left-neighbour
+// samples cost 32 more registers).
+constexpr int G_CHUNK = 4;
+template <bool MAG, bool MEL, int TAIL = 0, bool PE = false>
+__global__ __launch_bounds__(256, TAIL == 1 ? 3 : 1) void gen_stft_kernel(const float* __restrict__ wav, long long stride, int N, int hop, int T,
                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
                                                        const float2* __restrict__ tw512, const float* __restrict__ peaks,
-                                                       int pre_emph, float coef, float* __restrict__ out, GenMel mel,
+                                                       float coef, float* __restrict__ out, GenMel mel,
                                                        long long n_rows /* clips x T */, GenTail tail) {
     static_assert(TAIL == 0 || (!MEL && MAG == (TAIL == 2)), "contrast rows from powers, the centroid from magnitudes");
     __shared__ float xs[4 * 4 * G_XFRAME];
     __shared__ float otile[G_NFREQ * (G_FPB + 1)];
     __shared__ float2 twl[16 * G_XROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, fsub = lane >> 4;
-    // the 16 frames of a workgroup are 16 consecutive (clip, frame) pairs of the launch: T is not padded to whole tiles
+    // the 16 frames of a tile are 16 consecutive (clip, frame) pairs of the launch: T is not padded to whole tiles
     const int f16 = wave * 4 + fsub;
-    const long long row0 = (long long)blockIdx.x * G_FPB, row = row0 + f16 < n_rows ? row0 + f16 : n_rows - 1;
-    const long long clip = row / T;
-    const int t = int(row - clip * T);
+    const long long n_tiles = (n_rows + G_FPB - 1) / G_FPB, tile0 = (long long)blockIdx.x * G_CHUNK;
+    const int ntile = int(n_tiles - tile0 < G_CHUNK ? n_tiles - tile0 : G_CHUNK);
     twl[(tid >> 4) * G_XROW + (tid & 15)] = tw256[tid];
     __syncthreads();
     const float2* tw_row = twl + j * G_XROW;
     const float2 tw_j = tw512[j];
-    const float* x = wav + clip * stride;
-    const PeakScale scale(peaks ? peaks[clip] : 0.f);   // "if max_val > 0: waveform / max_val" (:209-212)
-    auto sample = [&](int i) -> float { return scale(x[i]); };
-    auto value = [&](int i) -> float {   // sample i of the (normalised, pre-emphasised) signal, i already inside the clip
-        float v = sample(i);
-        if (pre_emph && i > 0) v = __fsub_rn(v, mul_rn(coef, sample(i - 1)));   // y[n] = x[n] - coef x[n-1], y[0] = x[0]
-        return v;
-    };
-    float2 a[16], z[16];
-    const int s0 = hop * t - G_PADL + 2 * j;
+    [[maybe_unused]] float2 wreg[TAIL == 1 ? 1 : 16];   // TAIL == 1: the selection networks need the registers, taps come from L1
+    if constexpr (TAIL != 1) {
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        int i0 = s0 + 32 * n1, i1 = i0 + 1;   // reflect padding (N >= 257: one reflection suffices)
-        i0 = i0 < 0 ? -i0 : (i0 >= N ? 2 * (N - 1) - i0 : i0);
-        i1 = i1 < 0 ? -i1 : (i1 >= N ? 2 * (N - 1) - i1 : i1);
-        const float2 w = *reinterpret_cast<const float2*>(win + 32 * n1 + 2 * j);
-        a[n1] = make_float2(value(i0) * w.x, value(i1) * w.y);
+        for (int n1 = 0; n1 < 16; ++n1) wreg[n1] = *reinterpret_cast<const float2*>(win + 32 * n1 + 2 * j);
     }
+    // raw samples of this lane's frame of one tile (and, PE, their left neighbours in clip order; 0 in front of the clip: y[0] = x[0])
+    float2 raw[16];
+    [[maybe_unused]] float2 rawl[PE ? 16 : 1];
+    float pk = 0.f;
+    auto load_tile = [&](long long tile) {
+        const long long r0 = tile * G_FPB, row = r0 + f16 < n_rows ? r0 + f16 : n_rows - 1;
+        const long long clip = row / T;
+        const int t = int(row - clip * T);
+        const float* x = wav + clip * stride;
+        pk = peaks ? peaks[clip] : 0.f;
+        const int s0 = hop * t - G_PADL + 2 * j;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            int i0 = s0 + 32 * n1, i1 = i0 + 1;   // reflect padding (N >= 257: one reflection suffices)
+            i0 = i0 < 0 ? -i0 : (i0 >= N ? 2 * (N - 1) - i0 : i0);
+            i1 = i1 < 0 ? -i1 : (i1 >= N ? 2 * (N - 1) - i1 : i1);
+            raw[n1] = make_float2(x[i0], x[i1]);
+            if constexpr (PE) rawl[n1] = make_float2(i0 > 0 ? x[i0 - 1] : 0.f, i1 > 0 ? x[i1 - 1] : 0.f);
+        }
+    };
+    load_tile(tile0);
+#pragma unroll 1
+    for (int c = 0; c < ntile; ++c) {
+    const long long row0 = (tile0 + c) * G_FPB;
+    float2 a[16], z[16];
+    {
+        const PeakScale scale(pk);   // "if max_val > 0: waveform / max_val" (:209-212)
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            float v0 = scale(raw[n1].x), v1 = scale(raw[n1].y);
+            if constexpr (PE) {   // y[n] = x[n] - coef x[n-1], y[0] = x[0] (:235-238), on the normalised signal
+                v0 = __fsub_rn(v0, mul_rn(coef, scale(rawl[n1].x)));
+                v1 = __fsub_rn(v1, mul_rn(coef, scale(rawl[n1].y)));
+            }
+            const float2 wt = TAIL == 1 ? *reinterpret_cast<const float2*>(win + 32 * n1 + 2 * j) : wreg[TAIL == 1 ? 0 : n1];
+            a[n1] = make_float2(v0 * wt.x, v1 * wt.y);
+        }
+    }
+    if (c + 1 < ntile) load_tile(tile0 + c + 1);   // lands while this tile's FFTs run
     dft16(a);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], tw_row[k1]);
@@ -187,7 +216,10 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
     }
     if (j == 0) put(128, 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y));   // X[128] = conj Z[128]
     __syncthreads();
-    if constexpr (TAIL == 1) {   // raw contrast rows (:272-293): thread = (frame f of the tile, band i)
+    if constexpr (TAIL == 1) {
+        // raw contrast rows (:272-293): thread = (frame f of the tile, band i), a selection network per thread (contrast_rank.h).
+        // (Ranking a band's bins with 16 threads per frame -- every thread busy -- issues more instructions in total, 4.0 k against
+        // 3.1 k wave-instructions per tile, and was slower: the idle SIMDs here serve the CU's other workgroups.)
         const int f = tid & 15, i = tid >> 4;
         const long long orow = row0 + f;
         if (i < tail.cfg.n_bands && orow < n_rows) {
@@ -195,9 +227,9 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
             int low = tail.cfg.edges[i], high = tail.cfg.edges[i + 1];
             if (high <= low) high = low + 1;
             if (high > G_NFREQ) high = G_NFREQ;
-            float pk, valleys, chk = 0.f;
-            contrast_select(otile + low * (G_FPB + 1) + f, G_FPB + 1, high - low, 1.0f, pk, valleys, chk);
-            out[(oclip * tail.nfeat + tail.row0 + i) * T + (orow - oclip * T)] = (log1pf(pk) - log1pf(valleys)) + chk;
+            float peaks_mean, valleys, chk = 0.f;
+            contrast_select<13>(otile + low * (G_FPB + 1) + f, G_FPB + 1, high - low, 1.0f, peaks_mean, valleys, chk);   // nb <= 64
+            out[(oclip * tail.nfeat + tail.row0 + i) * T + (orow - oclip * T)] = (log1pf(peaks_mean) - log1pf(valleys)) + chk;
         }
     } else if constexpr (TAIL == 2) {   // torchaudio.functional.spectral_centroid / (sample_rate / 2), :295-298
         const int f = tid & 15, grp = tid >> 4;
@@ -262,6 +294,8 @@ __global__ __launch_bounds__(256) void gen_stft_kernel(const float* __restrict__
         float* o = out + oclip * (long long)G_NFREQ * T + (orow - oclip * T);
         for (int k = tid >> 4; k < G_NFREQ; k += 16)
             if (live) o[(long long)k * T] = otile[k * (G_FPB + 1) + f];
+    }
+    __syncthreads();   // the tile of powers and the transpose scratch are written again by the next tile
     }
 }
 
@@ -785,8 +819,13 @@ void gen_launch_stft(const GenFeat* g, int N, int T, const float* w, long long w
                      int pre_emph, float coef, float* out, const GenMel& mel, hipStream_t stream) {
     if (g->nfft == G_NFFT) {
         const long long n_rows = (long long)nc * T;
-        hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), dim3((unsigned)((n_rows + G_FPB - 1) / G_FPB)), dim3(256), 0, stream, w,
-                           wav_stride, N, g->hop, T, win, g->tw256, g->tw512, peaks, pre_emph, coef, out, mel, n_rows, GenTail{});
+        const dim3 gs((unsigned)((n_rows + G_FPB * G_CHUNK - 1) / (G_FPB * G_CHUNK)));
+        if (MEL && pre_emph)
+            hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL, 0, MEL>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, win, g->tw256,
+                               g->tw512, peaks, coef, out, mel, n_rows, GenTail{});
+        else
+            hipLaunchKernelGGL((gen_stft_kernel<MAG, MEL>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, win, g->tw256,
+                               g->tw512, peaks, coef, out, mel, n_rows, GenTail{});
     } else if (g->nfft >= 64 && (g->nfft & (g->nfft - 1)) == 0) {
         hipLaunchKernelGGL((gen_stft_pow2_kernel<MAG, MEL>), dim3((T + 3) / 4, nc), dim3(256), pow2_lds_bytes(g->nfft), stream, w,
                            wav_stride, N, g->hop, T, g->nfft, win, g->twn, peaks, pre_emph, coef, out, mel);
@@ -972,11 +1011,11 @@ int gen_frames(const GenFeat* g, int n_samples) {
 }
 
 namespace {
-// n_fft = 512 with bands of <= 128 bins (every geometric band layout of 257 bins): the contrast and centroid rows come straight out of
+// n_fft = 512 with bands of <= 64 bins (every geometric band layout of 257 bins): the contrast and centroid rows come straight out of
 // the STFT workgroups' tiles (gen_stft_kernel TAIL) -- no spectrogram in the workspace
 bool contrast_in_stft(const GenFeat* g, int n_bands, const int* edges) {
     bool ok = g->nfft == G_NFFT && n_bands >= 1 && n_bands <= 16;
-    for (int i = 0; ok && i < n_bands; ++i) ok = edges[i + 1] - edges[i] <= G_CT_BINS;
+    for (int i = 0; ok && i < n_bands; ++i) ok = edges[i + 1] - edges[i] <= 64;   // (1 .. 16 geometric bands of 257 bins: <= 64 bins)
     return ok;
 }
 struct GenCarve {
@@ -1067,12 +1106,12 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
             // from the un-emphasised (normalised) signal (:476-478)
             if (narrow) {   // n_fft = 512: rows straight out of the STFT workgroups' tiles
                 const long long n_rows = (long long)nc * T;
-                const dim3 gs((unsigned)((n_rows + G_FPB - 1) / G_FPB));
+                const dim3 gs((unsigned)((n_rows + G_FPB * G_CHUNK - 1) / (G_FPB * G_CHUNK)));
                 const GenTail tail{contrast, g->freqs, float(g->sample_rate) / 2.0f, nfeat, nbase};
                 hipLaunchKernelGGL((gen_stft_kernel<false, false, 1>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, g->win,
-                                   g->tw256, g->tw512, pk, 0, 0.f, feat, none, n_rows, tail);
+                                   g->tw256, g->tw512, pk, 0.f, feat, none, n_rows, tail);
                 hipLaunchKernelGGL((gen_stft_kernel<true, false, 2>), gs, dim3(256), 0, stream, w, wav_stride, N, g->hop, T, g->win_full,
-                                   g->tw256, g->tw512, pk, 0, 0.f, feat, none, n_rows, tail);
+                                   g->tw256, g->tw512, pk, 0.f, feat, none, n_rows, tail);
                 hipLaunchKernelGGL(gen_zscore_kernel, dim3(nc), dim3(256), 0, stream, feat, nfeat, T, nbase, contrast.n_bands + 1);
                 COUGH_HIP_CHECK(hipGetLastError());
                 continue;
