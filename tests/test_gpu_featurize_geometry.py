@@ -205,3 +205,22 @@ def test_pipeline_on_a_runtime_geometry_with_contrast_rows():
     err = (logits.cpu() - ref_l).abs().max().item()
     print(f"pipeline on 94 x 51 images: logits max abs err {err:.2e}")
     assert err < 1e-3 and torch.equal(logits.cpu().argmax(1), ref_l.argmax(1))
+
+
+def test_runtime_geometry_more_clips_than_one_sub_batch():
+    """33 000 quarter-second clips with contrast rows: the contrast kernels run in sub-batches of at most 32 768 clips behind ONE
+    launch of the one-launch kernel; every clip equals its own result in a batch of four (size-independent property)."""
+    flags = {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 2, "use_pre_emphasis": True}
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=0.25, **BASE, **flags)
+    assert pre.kernel_path() == "tuned_geometry"
+    from cough_detector_amd import synth
+    base = synth.device_clips(0, 8250)                                   # 8250 x 16000 -> 33 000 clips of 4000 samples
+    w = base.reshape(33000, 4000)
+    f = pre.featurize_batch(w, normalize=True)
+    assert f.shape == (33000, 93, 26) and torch.isfinite(f).all()
+    for i in (0, 32766, 32768, 32999):
+        a = i - i % 4 if i + 4 <= 33000 else 32996
+        small = pre.featurize_batch(w[a:a + 4].contiguous(), normalize=True)
+        assert torch.equal(small, f[a:a + 4]), i
+    ref = ofeat.extract_features_batch(w[32990:33000].cpu(), normalize_first=True, **ofeat.geometry_kwargs(**BASE), **flags)
+    assert (f[32990:].cpu() - ref).abs().max().item() < 2e-4
