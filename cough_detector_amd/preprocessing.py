@@ -127,6 +127,7 @@ class AudioPreprocessor:
         self._handle_lock = threading.Lock()
         self._ws = {}                               # stream -> scratch of the spectral-contrast rows / the generic kernel chain
         self._resamplers = {}
+        self._plain: Optional["AudioPreprocessor"] = None   # helper methods: the same transforms without pre-emphasis / contrast
 
     # ------------------------------------------------------------------ native handle
     def _native(self) -> C.c_void_p:
@@ -390,13 +391,30 @@ class AudioPreprocessor:
             raise ValueError(f"extract_features: expected (1, N) or (B, N), got {tuple(waveform.shape)}")
         return self.featurize_batch(waveform).to(self._out_device(waveform))      # any length, as the reference (:432-489)
 
+    def _without_pre_emphasis(self) -> "AudioPreprocessor":
+        """extract_mel_spectrogram / extract_mfcc called on their own transform the waveform AS GIVEN: the reference applies
+        pre-emphasis in extract_features only (src/preprocessing.py:455-459), not in these methods (:387-430)."""
+        if not self.use_pre_emphasis:
+            return self
+        with self._handle_lock:
+            if self._plain is None:
+                self._plain = AudioPreprocessor(
+                    sample_rate=self.sample_rate, n_mels=self.n_mels, n_fft=self.n_fft, hop_length=self.hop_length,
+                    win_length=self.win_length, f_min=self.f_min, f_max=self.f_max, segment_duration=self.segment_duration,
+                    n_mfcc=self.n_mfcc, use_mfcc=self.use_mfcc, use_pcen=self.use_pcen, use_pre_emphasis=False,
+                    pre_emphasis_coef=self.pre_emphasis_coef, use_delta_delta=False, use_spectral_contrast=False,
+                    n_contrast_bands=self.n_contrast_bands, device=self.device)
+        return self._plain
+
     def extract_mel_spectrogram(self, waveform: torch.Tensor) -> torch.Tensor:
-        return self.extract_features(waveform)[:, :self.n_mels]
+        """(1, N) -> (1, n_mels, T): src/preprocessing.py:387-412 (log-mel or PCEN rows of the waveform as given)."""
+        return self._without_pre_emphasis().extract_features(waveform)[:, :self.n_mels]
 
     def extract_mfcc(self, waveform: torch.Tensor) -> torch.Tensor:
+        """(1, N) -> (1, n_mfcc, T): src/preprocessing.py:414-430 (z-scored MFCCs of the waveform as given)."""
         if not self.use_mfcc:
             raise ValueError("extract_mfcc: this preprocessor was built with use_mfcc=False")
-        return self.extract_features(waveform)[:, self.n_mels:self.n_mels + self.n_mfcc]
+        return self._without_pre_emphasis().extract_features(waveform)[:, self.n_mels:self.n_mels + self.n_mfcc]
 
     def extract_spectral_contrast(self, waveform: torch.Tensor) -> torch.Tensor:
         """(1, N) -> (1, n_contrast_bands + 1, T): the rows src/preprocessing.py:242-303 appends."""

@@ -392,3 +392,26 @@ def test_contrast_selection_networks_of_every_size(monkeypatch, edges):
         err = (got - ref).abs().max().item()
         print(f"edges {edges} normalize={normalize}: abs err {err:.2e}")
         assert err < 2e-5
+
+
+def test_mel_and_mfcc_helpers_transform_the_waveform_as_given():
+    """extract_mel_spectrogram / extract_mfcc called on their own (/root/reference/src/preprocessing.py:387-430) do NOT apply
+    pre-emphasis -- extract_features does that before calling them (:455-459) -- also on a preprocessor built with
+    use_pre_emphasis=True; extract_spectral_contrast (:242-303) never sees the emphasised signal either."""
+    flags = dict(use_pcen=False, use_pre_emphasis=True, use_delta_delta=True, use_spectral_contrast=True, n_contrast_bands=4)
+    pre = cda.AudioPreprocessor(device="cuda", **flags)
+    w = synth_batch(720, 1, peak_normalize=True)
+    plain = ofeat.extract_features_batch(w, **{**flags, "use_pre_emphasis": False})
+    emph = ofeat.extract_features_batch(w, **flags)
+    assert (plain[:, :64] - emph[:, :64]).abs().max().item() > 1e-2             # the flag matters on this clip
+    mel, mfcc, con = pre.extract_mel_spectrogram(w.cuda()), pre.extract_mfcc(w.cuda()), pre.extract_spectral_contrast(w.cuda())
+    assert mel.shape == (1, 64, 101) and mfcc.shape == (1, 13, 101) and con.shape == (1, 5, 101)
+    assert (mel.cpu() - plain[:, :64]).abs().max().item() < FEAT_TOL
+    assert ((mfcc.cpu() - plain[:, 64:77]).abs() / plain[:, 64:77].abs().clamp(min=1.0)).max().item() < FEAT_TOL
+    assert (con.cpu() - emph[:, -5:]).abs().max().item() < 2e-4                  # same rows with and without the flag
+    full = pre.extract_features(w.cuda()).cpu()                                 # the whole image still is the emphasised one
+    assert (full[:, :64] - emph[:, :64]).abs().max().item() < FEAT_TOL
+    # PCEN branch of the helper (:400-404)
+    pp = cda.AudioPreprocessor(device="cuda", **{**flags, "use_pcen": True, "use_spectral_contrast": False})
+    ref = ofeat.extract_features_batch(w, use_pcen=True, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
+    assert (pp.extract_mel_spectrogram(w.cuda()).cpu() - ref[:, :64]).abs().max().item() < FEAT_TOL
