@@ -193,8 +193,30 @@ class AudioPreprocessor:
 
     # ------------------------------------------------------------------ reference helpers (host plumbing)
     def load_audio(self, path: str):
-        raise ValueError("load_audio: file decoding (torchaudio.load) is outside the MI355X hot path; "
-                         "decode to a float32 tensor and call process()")
+        """``torchaudio.load(path)`` for RIFF/WAVE files (src/preprocessing.py:155-166): (channels, samples) float32 in
+        [-1, 1) and the sample rate.  Host plumbing (scipy.io.wavfile); integer PCM is scaled as torchaudio's
+        ``normalize=True`` does (8-bit unsigned: (x - 128) / 128; 16 / 24 / 32-bit: / 2^(bits - 1)).  Other containers are outside
+        the MI355X hot path: decode them to a float32 tensor and call process()."""
+        import numpy as np
+        try:
+            from scipy.io import wavfile
+            sr, data = wavfile.read(path)
+        except Exception as e:      # noqa: BLE001  (not a WAVE file, or a codec scipy does not read)
+            raise ValueError(f"load_audio: {path!r} is not a PCM / float WAVE file this build decodes ({e}); decode it to a "
+                             "float32 tensor and call process()") from e
+        if data.ndim == 1:
+            data = data[:, None]
+        if data.dtype == np.uint8:
+            x = (data.astype(np.float32) - 128.0) / 128.0
+        elif data.dtype == np.int16:
+            x = data.astype(np.float32) / 32768.0
+        elif data.dtype == np.int32:                 # 32-bit PCM, and 24-bit PCM that scipy left-justifies in 32 bits
+            x = (data.astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif data.dtype in (np.float32, np.float64):
+            x = data.astype(np.float32)
+        else:
+            raise ValueError(f"load_audio: unsupported sample type {data.dtype}")
+        return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
 
     def resample(self, waveform: torch.Tensor, orig_sr: int) -> torch.Tensor:
         """T.Resample(orig_sr, sample_rate) on the GPU (``cough_resample``); (C, N) -> (C, ceil(N*sr/orig_sr))."""

@@ -300,7 +300,6 @@ def test_rebind_to_the_numa_node_of_the_device_the_runtime_really_gave(tmp_path)
 def test_effective_dtype_reports_the_kernels_that_run():
     """A reduced-precision request the compiled kernels do not cover is reported (and warned about at the first
     forward, tests/test_gpu_fuzz.py), not silently replaced."""
-    import cough_detector_amd as cda
     m = cda.create_model("residual", n_mels=90, compute_dtype="bf16x3")
     assert m.compute_dtype == "bf16x3" and m.effective_dtype() == "bf16x3" and m.effective_dtype(80, 101) == "fp32"
     assert m.effective_dtype(103, 101) == "bf16x3" and m.effective_dtype(110, 101) == "bf16x3"     # the reference's own flags
@@ -343,3 +342,31 @@ def test_probability_logs_are_bounded_and_a_zero_hop_is_refused():
             cda.RealtimePreprocessor(window_duration=1.0, hop_duration=hop, **SHIPPED)
     rt = cda.RealtimePreprocessor(window_duration=1.0, hop_duration=1.0 / 16000, **SHIPPED)
     assert rt.hop_samples == 1
+
+
+def test_load_audio_reads_wave_files_like_torchaudio_load(tmp_path):
+    """AudioPreprocessor.load_audio = torchaudio.load(path) (/root/reference/src/preprocessing.py:155-166) for WAVE files:
+    (channels, samples) float32 scaled to [-1, 1) and the file's sample rate; anything else is refused with a ValueError."""
+    from scipy.io import wavfile
+    pre = cda.AudioPreprocessor(**SHIPPED)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.9, 0.9, size=(4410, 2)).astype(np.float32)
+    cases = {"f32": (x, x), "i16": ((x * 32767).astype(np.int16), None), "u8": ((x * 127 + 128).astype(np.uint8), None),
+             "i32": ((x.astype(np.float64) * 2147483647).astype(np.int32), None)}
+    for name, (data, want) in cases.items():
+        path = str(tmp_path / f"{name}.wav")
+        wavfile.write(path, 44100, data)
+        w, sr = pre.load_audio(path)
+        assert sr == 44100 and w.shape == (2, 4410) and w.dtype == torch.float32 and w.is_contiguous()
+        if want is None:
+            scale = {"i16": 32768.0, "u8": 128.0, "i32": 2147483648.0}[name]
+            want = (data.astype(np.float64) - (128 if name == "u8" else 0)) / scale
+        assert np.abs(w.numpy().T - want).max() < 1e-6 and np.abs(w.numpy().T - x).max() < 2e-2      # (8-bit: 1 / 128 steps)
+    mono = str(tmp_path / "mono.wav")
+    wavfile.write(mono, 16000, (x[:, 0] * 32767).astype(np.int16))
+    w, sr = pre.load_audio(mono)
+    assert w.shape == (1, 4410) and sr == 16000
+    bad = tmp_path / "not_audio.wav"
+    bad.write_bytes(b"ID3 definitely not RIFF")
+    with pytest.raises(ValueError, match="load_audio"):
+        pre.load_audio(str(bad))
