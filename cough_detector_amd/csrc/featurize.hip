@@ -1360,6 +1360,12 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
                       "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
         peak_out = contrast_peaks(d_workspace, n_clips);
+    } else if (f->contrast.n_bands > 0 && norm) {   // run-time geometry: the generic chain's layout, peaks of the call at its head
+        COUGH_REQUIRE(d_workspace && workspace_bytes >= gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips) &&
+                          (reinterpret_cast<size_t>(d_workspace) & 255) == 0,
+                      COUGH_EWORKSPACE, "spectral contrast needs a 256-byte aligned workspace of "
+                      "cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
+        peak_out = static_cast<float*>(d_workspace);
     }
     // one instantiation per (pre-emphasis, stem, full-band filterbank, 103-row stem); everything else is a run-time argument
     const bool full = f->kind >= 2, pe = f->cfg.use_pre_emphasis != 0;

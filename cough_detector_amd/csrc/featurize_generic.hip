@@ -1031,8 +1031,8 @@ GenCarve gen_carve(const GenFeat* g, bool contrast, int T, int n_clips) {
     if (sub > 32768) sub = 32768;   // grid.y
     if (sub > size_t(n_clips)) sub = size_t(n_clips);
     c.sub = int(sub);
-    c.o_peaks = 0;
-    c.o_stat = c.o_peaks + align256g(sub * 4);
+    c.o_peaks = 0;   // one peak per clip of the CALL (the one-launch kernel leaves them for the contrast rows of a run-time geometry)
+    c.o_stat = c.o_peaks + align256g(size_t(n_clips) * 4);
     c.o_P = c.o_stat + align256g(sub * 16);
     c.o_M = c.o_P + (contrast ? align256g(sub * spec) : 0);
     c.o_mel = c.o_M + (contrast ? align256g(sub * spec) : 0);
@@ -1086,8 +1086,11 @@ int gen_featurize(const GenFeat* g, const cough_feat_config& cfg, const Contrast
         const int nc = n_clips - c0 < c.sub ? n_clips - c0 : c.sub;
         const float* w = d_wav + (long long)c0 * wav_stride;
         float* feat = d_feat + (long long)c0 * nfeat * T;
-        const float* pk = normalize ? peaks : nullptr;
-        if (normalize) hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, N, peaks);
+        // contrast_rows_only: the featurise kernel has left every clip's peak at the head of the workspace (a NaN sample is not in
+        // it -- v_max drops NaNs -- but poisons its frames, and the joint z-score of the rows spreads that over the clip)
+        const float* pk = normalize ? (contrast_rows_only ? peaks + c0 : peaks) : nullptr;
+        if (normalize && !contrast_rows_only)
+            hipLaunchKernelGGL(gen_peak_kernel, dim3(nc), dim3(256), 0, stream, w, wav_stride, N, peaks);
         const dim3 gt((T + G_TT - 1) / G_TT, nc);
         // STFT + mel projection in one kernel: the power spectrogram of the (pre-emphasised) signal is never materialised
         const GenMel gm{n_mels, g->mel_lo, g->mel_hi, g->mel_off, g->mel_w, g->n_taps}, none{0, nullptr, nullptr, nullptr, nullptr, 0};
