@@ -178,8 +178,11 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps, int n_frames = NFRAMES) 
 // lane are live), segment length (the dB buffer of n_mels x frames must fit the LDS of two workgroups per CU: 201 frames of 64 bands), i.e. other
 // sample rates / window durations on the one-launch kernel
 // instead of the generic chain.  Samples arrive as 4-byte loads (no alignment contract), two workgroups per CU.
+#ifndef COUGH_GEO_WG_PER_CU
+#define COUGH_GEO_WG_PER_CU 2   // run-time geometry: 188 VGPRs; three per CU spill 21-33 (measured: profiles/r05_runtime_geometry_featuriser.txt)
+#endif
 template <bool PRE_EMPH, int STEM, bool FULL = false, bool TALL = false, bool PCS = false, bool GEO = false>
-__global__ __launch_bounds__(THREADS, GEO ? 2 : 3) void featurize_kernel(
+__global__ __launch_bounds__(THREADS, GEO ? COUGH_GEO_WG_PER_CU : 3) void featurize_kernel(
     const float* __restrict__ wav, long long wav_stride, float* __restrict__ out, int nfeat,
     const FeatTables* __restrict__ tb, int normalize, float pre_coef, int delta_delta /* 0: MFCC + delta rows,
     1: + delta-delta, 2: no MFCC rows */, int pcen, StemFuse stem, FullBank fbk,
