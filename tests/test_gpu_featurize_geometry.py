@@ -224,3 +224,36 @@ def test_runtime_geometry_more_clips_than_one_sub_batch():
         assert torch.equal(small, f[a:a + 4]), i
     ref = ofeat.extract_features_batch(w[32990:33000].cpu(), normalize_first=True, **ofeat.geometry_kwargs(**BASE), **flags)
     assert (f[32990:].cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_raw_c_abi_argument_errors_on_the_runtime_geometry_path():
+    """cough_featurize_any on a run-time-geometry handle with contrast rows: a missing / short / misaligned workspace and a row
+    stride below the segment length come back as error codes with a message (ValueError / RuntimeError through _lib.check),
+    never as a launch."""
+    from cough_detector_amd import _lib
+    flags = {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 2}
+    pre = cda.AudioPreprocessor(device="cuda", segment_duration=0.5, **BASE, **flags)
+    lib, h = _lib.load(), pre._native()
+    assert lib.cough_featurizer_path(h) == _lib.PATH_TUNED_GEOMETRY
+    b, n = 6, 8000
+    w = torch.randn(b, n, device="cuda")
+    out = torch.empty(b, pre.get_num_features(), 51, device="cuda")
+    need = lib.cough_featurizer_workspace_bytes_for(h, n, b)
+    assert need > 0
+    ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
+    base = ws.data_ptr() + (-ws.data_ptr()) % 256
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(stride=n, wsp=base, wsb=need, flags_=_lib.FEAT_NORMALIZE):
+        return lib.cough_featurize_any(h, w.data_ptr(), stride, n, out.data_ptr(), b, flags_, wsp, wsb, st)
+    assert call() == _lib.OK
+    good = out.clone()
+    for kw in (dict(wsp=None, wsb=0), dict(wsb=need - 1), dict(wsp=base + 4)):
+        rc = call(**kw)
+        assert rc != _lib.OK and b"workspace" in lib.cough_amd_last_error()
+        with pytest.raises((RuntimeError, ValueError), match="workspace"):
+            _lib.check(rc, "cough_featurize_any")
+    rc = call(stride=n - 1)
+    assert rc == _lib.EINVAL and b"stride" in lib.cough_amd_last_error()
+    assert call(flags_=0) == _lib.OK                                      # without normalize the peaks are not needed: still fine
+    assert call() == _lib.OK and torch.equal(out, good)                   # and the handle is unharmed
