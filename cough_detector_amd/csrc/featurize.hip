@@ -174,7 +174,7 @@ constexpr size_t full_lds_bytes(int n_mels, int n_taps, int n_frames = NFRAMES) 
 // PCS: the fused stem's mel rows are the PCEN values (use_pcen with a fused stem) -- a template parameter because the values
 // wait in 26 registers from the PCEN branch to the image build, which costs the shipped instantiation 1.3 % when it is a run-time
 // choice (same-box A/B, profiles/r05_bench_flags.txt).
-// GEO (with FULL, no stem): run-time STFT geometry at n_fft = 512 -- any hop <= 256, window <= 512 (all 16 sample pairs of a
+// GEO (with FULL, no stem): run-time STFT geometry at n_fft = 512 -- any hop <= 256 (up to 512 when the spans still cover the segment), window <= 512 (all 16 sample pairs of a
 // lane are live), segment length (the dB buffer of n_mels x frames must fit the LDS of two workgroups per CU: 201 frames of 64 bands), i.e. other
 // sample rates / window durations on the one-launch kernel
 // instead of the generic chain.  Samples arrive as 4-byte loads (no alignment contract), two workgroups per CU.
@@ -1119,7 +1119,11 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     // lengths whose dB buffer fits (64 bands: up to 222 frames); contrast rows come from the generic chain's kernels behind it
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
     const bool geo_ok = !stft_ok && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
-                        cfg->hop_length <= NFFT / 2 && cfg->segment_samples > NFFT / 2 && geo_frames <= 1024 &&
+                        // the frames' 512-sample spans must cover every sample (the fused normalise collects the peak from them):
+                        // always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the segment
+                        (cfg->hop_length <= NFFT / 2 ||
+                         (cfg->hop_length <= NFFT && (geo_frames - 1) * cfg->hop_length + NFFT / 2 >= cfg->segment_samples)) &&
+                        cfg->segment_samples > NFFT / 2 && geo_frames <= 1024 &&
                         (!cfg->use_pcen || geo_frames <= 208) &&   // PCEN: a thread keeps its quarter of a band's frames in 52 registers
                         (!cfg->use_mfcc || size_t(cfg->n_mfcc) * geo_frames * 4 <= LDS_XCH_FULL);
     bool full = false;

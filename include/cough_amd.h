@@ -101,7 +101,8 @@ int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_ti
 #define COUGH_PATH_GENERIC 0
 #define COUGH_PATH_TUNED 1
 #define COUGH_PATH_TUNED_FULLBAND 2
-#define COUGH_PATH_TUNED_GEOMETRY 3 /* one launch, run-time STFT geometry: n_fft 512, any window, hop <= 256, segments whose
+#define COUGH_PATH_TUNED_GEOMETRY 3 /* one launch, run-time STFT geometry: n_fft 512, any window, hop <= 256 (<= 512 while the
+                                     * frames' spans still cover the segment), segments whose
                                      * n_mels x frames dB buffer fits the LDS (64 bands: ~220 frames; other sample rates / window
                                      * durations), any filterbank; spectral-contrast rows are added by the generic STFT kernel behind it
                                      * (needs the workspace) */

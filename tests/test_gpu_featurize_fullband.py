@@ -59,7 +59,7 @@ def test_which_constructor_calls_land_on_which_kernels():
     assert path(hop_length=128, win_length=512) == "tuned_geometry" and path(win_length=37, hop_length=77, n_mels=20, segment_duration=0.5) == "tuned_geometry"
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=4) == "tuned_geometry"   # (contrast rows: generic kernels)
     assert path(hop_length=100) == "tuned_geometry" and path(segment_duration=2.0) == "tuned_geometry"      # 161 / 201 frames
-    assert path(hop_length=300) == "generic" and path(segment_duration=5.0) == "generic"           # hop > 256; 501 frames x 64 bands
+    assert path(hop_length=600) == "generic" and path(segment_duration=5.0) == "generic"           # hop > 512; 501 frames x 64 bands
     assert path(n_fft=400) == "generic"
 
 

@@ -38,6 +38,8 @@ GEO = {      # name -> (geometry overrides, segment seconds)
     "two_seconds_fmax8k_20mfcc": (dict(f_max=8000.0, n_mfcc=20), 2.0),
     "five_seconds_20mel_8mfcc_501_frames": (dict(n_mels=20, n_mfcc=8), 5.0),
     "hop31_130_frames": (dict(hop_length=31, win_length=100), 0.25),
+    "hop300_spans_still_cover_the_segment": (dict(hop_length=300), 1.0),
+    "hop512_win512": (dict(hop_length=512, win_length=512), 1.0),
 }
 
 
@@ -121,7 +123,7 @@ def test_runtime_geometry_flags(name, flags):
 def test_what_stays_on_the_generic_chain():
     def path(seconds=1.0, **kw):
         return cda.AudioPreprocessor(device="cuda", segment_duration=seconds, **{**BASE, **SHIPPED, **kw}).kernel_path()
-    assert path(hop_length=257) == "generic"                                       # frames would not overlap the packed pairs
+    assert path(hop_length=513) == "generic" and path(0.99, hop_length=500) == "generic"   # samples between / behind the frames' spans
     assert path(5.0) == "generic" and path(2.0, n_mels=80, f_max=8000.0) == "generic"            # 64 x 501 / 80 x 201 dB values
     assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "tuned_geometry"   # rows [0, nbase) in one launch
