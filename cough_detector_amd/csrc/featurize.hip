@@ -1118,7 +1118,9 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
     // lengths whose dB buffer fits (64 bands: up to 222 frames); contrast rows come from the generic chain's kernels behind it
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
-    const bool geo_ok = !stft_ok && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
+    // (an odd number of mel bands or more than 20 MFCCs take this kernel at the shipped STFT too: the fixed-geometry kernels store the
+    // mel rows in pairs and keep the MFCC and delta rows side by side in the 16 640-byte scratch; here the deltas lie over the dB buffer)
+    const bool geo_ok = (!stft_ok || cfg->n_mels % 2 != 0 || (cfg->use_mfcc && cfg->n_mfcc > FULL_MAX_MFCC)) && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
                         // the frames' 512-sample spans must cover every sample (the fused normalise collects the peak from them):
                         // always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the segment
                         (cfg->hop_length <= NFFT / 2 ||
@@ -1127,8 +1129,8 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                         (!cfg->use_pcen || geo_frames <= 208) &&   // PCEN: a thread keeps its quarter of a band's frames in 52 registers
                         (!cfg->use_mfcc || size_t(cfg->n_mfcc) * geo_frames * 4 <= LDS_XCH_FULL);
     bool full = false;
-    if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && cfg->n_mels % 2 == 0 &&
-        (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && cfg->n_mfcc <= FULL_MAX_MFCC && cfg->n_mfcc <= cfg->n_mels)) &&
+    if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && (cfg->n_mels % 2 == 0 || geo_ok) &&
+        (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && (cfg->n_mfcc <= FULL_MAX_MFCC || geo_ok) && cfg->n_mfcc <= cfg->n_mels)) &&
         (!cfg->use_pcen || cfg->n_mels == NMEL)) {
         const int nm = cfg->n_mels, nc = cfg->use_mfcc ? cfg->n_mfcc : 1;
         fb.n_mels = nm;
@@ -1163,7 +1165,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                 for (int m = 0; m < nm; ++m)
                     f_dct[((size_t(half) * chunks_per_half + r / fb.cw) * nm + m) * 8 + r % fb.cw] = dct[m * nc + c];
             }
-        fb.n_frames = stft_ok ? NFRAMES : geo_frames;
+        fb.n_frames = geo_ok ? geo_frames : NFRAMES;
         fb.n_samples = cfg->segment_samples;
         fb.hop = cfg->hop_length;
         full = full_lds_bytes(nm, fb.n_taps, fb.n_frames) <= 80 * 1024;   // at least two workgroups per CU
@@ -1218,7 +1220,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
     f->gen = gen;
-    f->kind = tuned ? 1 : full ? (stft_ok ? 2 : 3) : 0;
+    f->kind = tuned ? 1 : full ? (geo_ok ? 3 : 2) : 0;
     f->d_full = nullptr;
     f->full = fb;
     f->full_lds = full ? full_lds_bytes(fb.n_mels, fb.n_taps, fb.n_frames) : 0;

@@ -50,8 +50,10 @@ def test_which_constructor_calls_land_on_which_kernels():
     assert path(f_max=8000.0, use_pcen=True, use_pre_emphasis=True, use_delta_delta=True) == "tuned_fullband"
     assert path(f_max=8000.0, use_spectral_contrast=True, n_contrast_bands=4) == "tuned_fullband"
     assert path(f_max=8000.0, use_mfcc=False, n_mfcc=40) == "tuned_fullband"          # n_mfcc unused without MFCC rows
-    # outside: odd band counts, more than 20 MFCCs (their buffers alias the transpose scratch), PCEN off 64 bands, other STFTs
-    assert path(n_mels=63, f_max=8000.0) == "generic" and path(n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
+    # odd band counts / more than 20 MFCCs: the run-time-geometry kernel; outside: PCEN off 64 bands, other n_fft
+    assert path(n_mels=63, f_max=8000.0) == "tuned_geometry"      # odd band counts: the run-time-geometry kernel (element-wise stores)
+    assert path(n_mels=80, n_mfcc=21, f_max=8000.0) == "tuned_geometry" and path(n_mels=128, n_mfcc=40, f_max=8000.0) == "tuned_geometry"
+    assert path(n_mfcc=42) == "generic"                           # 42 x 101 MFCC values do not fit the 16 640-byte scratch
     assert path(n_mels=80, f_max=8000.0, use_pcen=True) == "generic"
     # n_fft = 512 with another hop / window / sample rate / segment of <= 128 frames: the full-band kernel with a run-time geometry
     assert path(hop_length=200) == "tuned_geometry" and path(segment_duration=0.5) == "tuned_geometry"

@@ -40,6 +40,12 @@ GEO = {      # name -> (geometry overrides, segment seconds)
     "hop31_130_frames": (dict(hop_length=31, win_length=100), 0.25),
     "hop300_spans_still_cover_the_segment": (dict(hop_length=300), 1.0),
     "hop512_win512": (dict(hop_length=512, win_length=512), 1.0),
+    "odd_63_mel_bands_at_the_shipped_stft": (dict(n_mels=63), 1.0),
+    "odd_13_mel_13_mfcc_hop200": (dict(n_mels=13, n_mfcc=13, hop_length=200), 1.0),
+    "odd_101_mel_bands_fmax8k": (dict(n_mels=101, n_mfcc=20, f_max=8000.0, f_min=0.0), 1.0),
+    "mel128_mfcc40_torchaudio_default_count": (dict(n_mels=128, n_mfcc=40, f_min=20.0, f_max=7600.0), 1.0),
+    "mfcc41_at_the_shipped_stft": (dict(n_mfcc=41), 1.0),
+    "mfcc33_hop200": (dict(n_mfcc=33, hop_length=200), 1.0),
 }
 
 
@@ -127,7 +133,8 @@ def test_what_stays_on_the_generic_chain():
     assert path(5.0) == "generic" and path(2.0, n_mels=80, f_max=8000.0) == "generic"            # 64 x 501 / 80 x 201 dB values
     assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "tuned_geometry"   # rows [0, nbase) in one launch
-    assert path(hop_length=200, n_mels=63) == "generic" and path(hop_length=200, n_mels=80, n_mfcc=21, f_max=8000.0) == "generic"
+    assert path(hop_length=200, n_mels=129, f_max=8000.0) == "generic" and path(hop_length=200, n_mfcc=52) == "generic"   # 52 x 81 x 4 B
+    assert path(n_mels=63, use_pcen=True) == "generic"                                           # PCEN: 64 bands
     assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
     assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS
     assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "tuned_geometry"

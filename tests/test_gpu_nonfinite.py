@@ -22,7 +22,7 @@ BAD_SAMPLES = {"nan_first": (0, NAN), "nan_middle": (8000, NAN), "nan_last": (15
                "minus_inf": (12345, -INF)}
 # the one-launch kernel (shipped sparse bank, full-band bank, run-time STFT geometry) and two geometries of the generic kernel chain
 GEOMETRIES = {"tuned": {}, "tuned_fullband_fmax8k": dict(f_max=8000.0), "tuned_geometry_hop200_40mel": dict(hop_length=200, n_mels=40),
-              "generic_nfft400": dict(n_fft=400), "generic_63_mel_bands": dict(n_mels=63), "tuned_geometry_hop100_161_frames": dict(hop_length=100)}
+              "generic_nfft400": dict(n_fft=400), "generic_42_mfcc": dict(n_mfcc=42), "tuned_geometry_hop100_161_frames": dict(hop_length=100)}
 
 
 def _oracle(w, normalize, geo, **flags):
@@ -162,7 +162,7 @@ def test_engine_keeps_a_nan_in_its_smoothing_history_like_the_reference(tmp_path
     assert events == ref_events and any(events)
 
 
-@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_63_mel_bands", "tuned_geometry_hop100_161_frames"])
+@pytest.mark.parametrize("geo", ["tuned", "tuned_fullband_fmax8k", "generic_42_mfcc", "tuned_geometry_hop100_161_frames"])
 def test_contrast_rows_of_extreme_peak_clips_under_normalize(geo):
     """The spectral-contrast rows come from a second STFT of the un-emphasised signal; with `normalize` the reference has divided
     by the peak first (:199-212, :476-478), so a denormal or huge clip gives the rows of the same clip at unit peak.  The tuned

@@ -21,7 +21,9 @@ CASES = [("shipped geometry (tuned one-launch kernel)", dict(), 4096),
          ("hop 128 / win 512 (126 frames)", dict(hop_length=128, win_length=512), 4096),
          ("hop 100 (161 frames)", dict(hop_length=100), 4096),
          ("hop 300 (54 frames)", dict(hop_length=300), 4096),
-         ("63 mel bands (generic chain)", dict(n_mels=63), 4096),
+         ("63 mel bands", dict(n_mels=63), 4096),
+         ("128 mel / 40 MFCC / f_max 8000", dict(n_mels=128, n_mfcc=40, f_max=8000.0), 4096),
+         ("42 MFCCs (generic chain)", dict(n_mfcc=42), 4096),
          ("n_fft 1024, win 400 (radix-4 Stockham kernel)", dict(n_fft=1024), 4096),
          ("n_fft 256, win 256, hop 128", dict(n_fft=256, win_length=256, hop_length=128), 4096),
          ("n_fft 400 = win (DFT on the f32 matrix cores)", dict(n_fft=400), 4096),
