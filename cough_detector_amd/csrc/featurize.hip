@@ -564,8 +564,9 @@ __global__ __launch_bounds__(THREADS, GEO ? COUGH_GEO_WG_PER_CU : 3) void featur
         // Run-time frame count (<= 208): thread = (band, quarter of the frames) walks its quarter in up to two chunks of 26 frames
         // -- the body of the fixed-geometry branch below -- and keeps the values in registers (two workgroups per CU: 256 VGPRs)
         // until the clip's minimum and maximum are known.
-        const int m = tid >> 2, quarter = (NF + 3) >> 2;
-        const int q0 = (tid & 3) * quarter, q1 = q0 + quarter < NF ? q0 + quarter : NF;
+        // Up to 64 bands: the threads of a band past the last one idle (an empty frame range; they read band 0).
+        const int mt = tid >> 2, m = mt < nmel ? mt : 0, quarter = (NF + 3) >> 2;
+        const int q0 = (tid & 3) * quarter, q1 = mt >= nmel ? q0 : q0 + quarter < NF ? q0 + quarter : NF;
         float lmin = INFINITY, lmax = -INFINITY;
         float pv[2][26];
 #pragma unroll
@@ -1118,9 +1119,10 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
     // lengths whose dB buffer fits (64 bands: up to 222 frames); contrast rows come from the generic chain's kernels behind it
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
-    // (an odd number of mel bands or more than 20 MFCCs take this kernel at the shipped STFT too: the fixed-geometry kernels store the
+    // (an odd number of mel bands, more than 20 MFCCs or PCEN with fewer than 64 bands take this kernel at the shipped STFT too: the fixed-geometry kernels store the
     // mel rows in pairs and keep the MFCC and delta rows side by side in the 16 640-byte scratch; here the deltas lie over the dB buffer)
-    const bool geo_ok = (!stft_ok || cfg->n_mels % 2 != 0 || (cfg->use_mfcc && cfg->n_mfcc > FULL_MAX_MFCC)) && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
+    const bool geo_ok = (!stft_ok || cfg->n_mels % 2 != 0 || (cfg->use_mfcc && cfg->n_mfcc > FULL_MAX_MFCC) ||
+                         (cfg->use_pcen && cfg->n_mels < NMEL)) && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
                         // the frames' 512-sample spans must cover every sample (the fused normalise collects the peak from them):
                         // always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the segment
                         (cfg->hop_length <= NFFT / 2 ||
@@ -1131,7 +1133,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     bool full = false;
     if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && (cfg->n_mels % 2 == 0 || geo_ok) &&
         (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && (cfg->n_mfcc <= FULL_MAX_MFCC || geo_ok) && cfg->n_mfcc <= cfg->n_mels)) &&
-        (!cfg->use_pcen || cfg->n_mels == NMEL)) {
+        (!cfg->use_pcen || cfg->n_mels == NMEL || (geo_ok && cfg->n_mels < NMEL))) {
         const int nm = cfg->n_mels, nc = cfg->use_mfcc ? cfg->n_mfcc : 1;
         fb.n_mels = nm;
         fb.n_mfcc = nc;

@@ -104,14 +104,15 @@ def test_runtime_geometry_against_oracle(name):
                          ids=["preemph", "dd", "pcen", "no_mfcc", "preemph_dd_pcen", "contrast4", "contrast3_preemph_dd",
                               "contrast1_wide_band_no_mfcc"])
 @pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel",
-                                  "two_seconds_201_frames"])
+                                  "two_seconds_201_frames", "odd_63_mel_bands_at_the_shipped_stft", "hop200_40mel",
+                                  "mel80_mfcc20_hop200"])
 def test_runtime_geometry_flags(name, flags):
     pre, g = _make(name, **flags)
     kw = {**SHIPPED, **flags}
     n, nm = pre.segment_samples, g["n_mels"]
     T = 1 + n // g["hop_length"]
-    # PCEN is built for 64 bands (thread = band x quarter of the frames): other band counts take the generic chain
-    want = "generic" if flags.get("use_pcen") and nm != 64 else "tuned_geometry"
+    # PCEN: thread = band x quarter of the frames, up to 64 bands; more bands take the generic chain
+    want = "generic" if flags.get("use_pcen") and nm > 64 else "tuned_geometry"
     assert pre.kernel_path() == want
     w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(6)]))
     got = pre.featurize_batch(w.cuda(), normalize=True)
@@ -134,7 +135,8 @@ def test_what_stays_on_the_generic_chain():
     assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "tuned_geometry"   # rows [0, nbase) in one launch
     assert path(hop_length=200, n_mels=129, f_max=8000.0) == "generic" and path(hop_length=200, n_mfcc=52) == "generic"   # 52 x 81 x 4 B
-    assert path(n_mels=63, use_pcen=True) == "generic"                                           # PCEN: 64 bands
+    assert path(n_mels=80, f_max=8000.0, hop_length=200, use_pcen=True) == "generic"             # PCEN: up to 64 bands
+    assert path(n_mels=40, use_pcen=True) == "tuned_geometry" and path(n_mels=63, use_pcen=True) == "tuned_geometry"
     assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
     assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS
     assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "tuned_geometry"
