@@ -1085,10 +1085,33 @@ struct cough_featurizer {
                          // 3 the full-band ones with a run-time STFT geometry (n_fft 512, hop <= 256)
     char* d_full;        // kind 2: CSR filterbank + DCT rows (one blob)
     cough::FullBank full;
-    size_t full_lds;     // kind 2: dynamic LDS of a workgroup
+    size_t full_lds;     // kind 2 / 3: dynamic LDS of a workgroup at the segment length
+    bool geo_any;        // the CSR tables exist and the run-time-geometry kernel can serve this configuration: waveforms of OTHER lengths
+                         // that fit its limits (geo_fits) take it too, whatever `kind` serves the segment
     cough::GenFeat* gen; // the generic kernel chain's tables (featurize_generic.hip): every geometry the tuned kernel does not
                          // cover, and -- for every featuriser -- waveforms of any other length (extract_features of any N)
 };
+
+namespace cough {
+namespace {
+// What the run-time-geometry instantiations (featurize_kernel<..., GEO>) take, whatever the waveform length ...
+bool geo_basic(const cough_feat_config& c) {
+    return c.n_fft == NFFT && c.win_length >= 1 && c.win_length <= NFFT && c.hop_length >= 1 && c.n_mels >= 2 && c.n_mels <= 128 &&
+           (!c.use_mfcc || (c.n_mfcc >= 1 && c.n_mfcc <= c.n_mels)) && (!c.use_pcen || c.n_mels <= NMEL);
+}
+// ... and for waveforms of n samples.  The frames' 512-sample spans must cover every sample (the fused normalise collects the peak
+// from them): always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the waveform.  PCEN: a thread keeps
+// its quarter of a band's frames in 52 registers.  The MFCC rows lie in the 16 640-byte transpose scratch (the deltas over the dead
+// dB buffer), the dB buffer of n_mels x frames in the LDS of two workgroups per CU.
+bool geo_fits(const cough_feat_config& c, int n_taps, int n) {
+    if (n <= NFFT / 2) return false;   // reflect padding
+    const long long T = n / c.hop_length + 1;
+    const bool covered = c.hop_length <= NFFT / 2 || (c.hop_length <= NFFT && (T - 1) * c.hop_length + NFFT / 2 >= n);
+    return covered && T <= 1024 && (!c.use_pcen || T <= 208) && (!c.use_mfcc || size_t(c.n_mfcc) * T * 4 <= LDS_XCH_FULL) &&
+           full_lds_bytes(c.n_mels, n_taps, int(T)) <= 80 * 1024;
+}
+}  // namespace
+}  // namespace cough
 
 extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_config* cfg,
                                        const float* window, const float* mel_fb, const float* dct) {
@@ -1117,23 +1140,12 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     std::vector<float> f_taps, f_dct;
     FullBank fb{};
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
-    // lengths whose dB buffer fits (64 bands: up to 222 frames); contrast rows come from the generic chain's kernels behind it
+    // lengths (geo_basic / geo_fits above), and at the shipped STFT what the fixed-geometry full-band kernels do not take: an odd
+    // number of mel bands (they store the mel rows in pairs), more than 20 MFCCs (they keep MFCC and delta rows side by side in the
+    // scratch), PCEN with fewer than 64 bands.  Contrast rows come from the generic chain's kernels behind it.
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
-    // (an odd number of mel bands, more than 20 MFCCs or PCEN with fewer than 64 bands take this kernel at the shipped STFT too: the fixed-geometry kernels store the
-    // mel rows in pairs and keep the MFCC and delta rows side by side in the 16 640-byte scratch; here the deltas lie over the dB buffer)
-    const bool geo_ok = (!stft_ok || cfg->n_mels % 2 != 0 || (cfg->use_mfcc && cfg->n_mfcc > FULL_MAX_MFCC) ||
-                         (cfg->use_pcen && cfg->n_mels < NMEL)) && cfg->n_fft == NFFT && cfg->win_length >= 1 && cfg->win_length <= NFFT && cfg->hop_length >= 1 &&
-                        // the frames' 512-sample spans must cover every sample (the fused normalise collects the peak from them):
-                        // always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the segment
-                        (cfg->hop_length <= NFFT / 2 ||
-                         (cfg->hop_length <= NFFT && (geo_frames - 1) * cfg->hop_length + NFFT / 2 >= cfg->segment_samples)) &&
-                        cfg->segment_samples > NFFT / 2 && geo_frames <= 1024 &&
-                        (!cfg->use_pcen || geo_frames <= 208) &&   // PCEN: a thread keeps its quarter of a band's frames in 52 registers
-                        (!cfg->use_mfcc || size_t(cfg->n_mfcc) * geo_frames * 4 <= LDS_XCH_FULL);
-    bool full = false;
-    if (!tuned && (stft_ok || geo_ok) && cfg->n_mels >= 2 && cfg->n_mels <= 128 && (cfg->n_mels % 2 == 0 || geo_ok) &&
-        (!cfg->use_mfcc || (cfg->n_mfcc >= 1 && (cfg->n_mfcc <= FULL_MAX_MFCC || geo_ok) && cfg->n_mfcc <= cfg->n_mels)) &&
-        (!cfg->use_pcen || cfg->n_mels == NMEL || (geo_ok && cfg->n_mels < NMEL))) {
+    const bool basic = geo_basic(*cfg);
+    if (basic) {   // the CSR tables: for kinds 2 and 3, and for waveforms of other lengths on any kind
         const int nm = cfg->n_mels, nc = cfg->use_mfcc ? cfg->n_mfcc : 1;
         fb.n_mels = nm;
         fb.n_mfcc = nc;
@@ -1167,11 +1179,12 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                 for (int m = 0; m < nm; ++m)
                     f_dct[((size_t(half) * chunks_per_half + r / fb.cw) * nm + m) * 8 + r % fb.cw] = dct[m * nc + c];
             }
-        fb.n_frames = geo_ok ? geo_frames : NFRAMES;
         fb.n_samples = cfg->segment_samples;
         fb.hop = cfg->hop_length;
-        full = full_lds_bytes(nm, fb.n_taps, fb.n_frames) <= 80 * 1024;   // at least two workgroups per CU
     }
+    bool fixed_full = !tuned && basic && stft_ok && cfg->n_mels % 2 == 0 && (!cfg->use_mfcc || cfg->n_mfcc <= FULL_MAX_MFCC) &&
+                      (!cfg->use_pcen || cfg->n_mels == NMEL) &&
+                      full_lds_bytes(cfg->n_mels, fb.n_taps, NFRAMES) <= 80 * 1024;   // at least two workgroups per CU
     if (cfg->use_spectral_contrast) {
         COUGH_REQUIRE(cfg->n_contrast_bands >= 1 && cfg->n_contrast_bands <= COUGH_MAX_CONTRAST_BANDS, COUGH_EUNSUPPORTED,
                       "n_contrast_bands = %d: the HIP path takes 1..%d", cfg->n_contrast_bands, COUGH_MAX_CONTRAST_BANDS);
@@ -1181,14 +1194,16 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
                           COUGH_EUNSUPPORTED, "spectral-contrast band %d = bins [%d, %d): the HIP path takes bands of <= 1024 bins "
                           "inside the spectrum", i, lo, hi);
             // the contrast kernel behind the persistent STFT passes (shipped geometry) selects out of bands of <= 128 bins
-            if (i < cfg->n_contrast_bands && hi - lo > 128 && stft_ok) tuned = full = false;
+            if (i < cfg->n_contrast_bands && hi - lo > 128 && stft_ok) tuned = fixed_full = false;
         }
     }
+    const bool geo_seg = !tuned && !fixed_full && basic && geo_fits(*cfg, fb.n_taps, cfg->segment_samples);
+    fb.n_frames = geo_seg ? geo_frames : NFRAMES;
     std::vector<FeatTables> host(1);
     FeatTables& t = host[0];
     std::memset(&t, 0, sizeof(t));
     const double PI = 3.14159265358979323846;
-    if (stft_ok || (full && geo_ok)) {   // the STFT tables of the one-launch kernels and of the persistent STFT kernel (spectrogram.hip)
+    if (stft_ok || basic) {   // the STFT tables of the one-launch kernels and of the persistent STFT kernel (spectrogram.hip)
         const int left = (NFFT - cfg->win_length) / 2;   // torch.stft centres a short window in the frame
         for (int n = 0; n < cfg->win_length; ++n) t.win[left + n] = window[n];
         for (int jj = 0; jj < 16; ++jj)
@@ -1222,10 +1237,11 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     cough_featurizer* f = new cough_featurizer();
     f->cfg = *cfg;
     f->gen = gen;
-    f->kind = tuned ? 1 : full ? (geo_ok ? 3 : 2) : 0;
+    f->kind = tuned ? 1 : fixed_full ? 2 : geo_seg ? 3 : 0;
     f->d_full = nullptr;
     f->full = fb;
-    f->full_lds = full ? full_lds_bytes(fb.n_mels, fb.n_taps, fb.n_frames) : 0;
+    f->full_lds = fixed_full || geo_seg ? full_lds_bytes(fb.n_mels, fb.n_taps, fb.n_frames) : 0;
+    f->geo_any = basic;
     f->nbase = cfg->use_mfcc ? cfg->n_mels + 2 * cfg->n_mfcc + (cfg->use_delta_delta ? cfg->n_mfcc : 0) : cfg->n_mels;
     f->nfeat = f->nbase + (cfg->use_spectral_contrast ? cfg->n_contrast_bands + 1 : 0);
     f->contrast.n_bands = cfg->use_spectral_contrast ? cfg->n_contrast_bands : 0;
@@ -1240,7 +1256,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     if (e == hipSuccess) e = hipMemcpy(f->d_win_full, hann.data(), NFFT * sizeof(float), hipMemcpyHostToDevice);
     // per-device kernel attributes (the persistent STFT kernel's 162 KB of dynamic LDS) on the creator's device
     if (e == hipSuccess && stft_prepare_device(&f->n_cus) != COUGH_OK) e = hipErrorUnknown;
-    if (e == hipSuccess && full) {
+    if (e == hipSuccess && basic) {
         // one blob: lo | hi | off (ints), taps, DCT rows; every piece 16-byte aligned
         auto al = [](size_t v) { return (v + 15) & ~size_t(15); };
         const size_t nm = size_t(fb.n_mels), o_hi = al(nm * 4), o_off = o_hi + al(nm * 4), o_w = o_off + al(nm * 4),
@@ -1321,6 +1337,12 @@ const GenFeat* featurizer_generic(const cough_featurizer* f) { return f->gen; }
 bool featurizer_tuned(const cough_featurizer* f, int n_samples) {
     return f->kind != 0 && (n_samples <= 0 || n_samples == f->cfg.segment_samples);
 }
+// Which kernels featurise waveforms of n_samples (0: the segment): 1 the handle's own one-launch kernel (kind 1 / 2 / 3 at the segment
+// length), 3 the run-time-geometry instantiation at ANOTHER length that fits its limits, 0 the generic kernel chain.
+static int featurizer_route(const cough_featurizer* f, int n_samples) {
+    if (n_samples <= 0 || n_samples == f->cfg.segment_samples) return f->kind != 0 ? 1 : 0;
+    return f->geo_any && geo_fits(f->cfg, f->full.n_taps, n_samples) ? 3 : 0;
+}
 bool featurizer_shipped_stft(const cough_featurizer* f, int n_samples) {   // the persistent STFT kernel's geometry
     return (f->kind == 1 || f->kind == 2) && (n_samples <= 0 || n_samples == NS);
 }
@@ -1334,10 +1356,11 @@ bool featurizer_stem_fusable(const cough_featurizer* f, bool x3) {
     return f->nfeat == ST_H && f->kind == 1 && !f->cfg.use_pre_emphasis && !f->cfg.use_pcen;
 }
 size_t featurizer_workspace_bytes(const cough_featurizer* f, int n_clips, int n_samples) {
-    if (!featurizer_tuned(f, n_samples)) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
+    const int route = featurizer_route(f, n_samples);
+    if (route == 0) return gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips);
     if (f->contrast.n_bands == 0 || n_clips <= 0) return 0;
     // contrast rows: behind the persistent STFT passes (shipped geometry), else by the generic chain's kernels
-    return f->kind == 3 ? gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips) : contrast_workspace_bytes(n_clips);
+    return route == 3 || f->kind == 3 ? gen_workspace_bytes(f->gen, f->cfg, n_samples, n_clips) : contrast_workspace_bytes(n_clips);
 }
 
 int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wav_stride, float* d_feat, int n_clips,
@@ -1345,19 +1368,21 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
                      int n_samples) {
     COUGH_REQUIRE(f && d_wav && (d_feat || stem), COUGH_EINVAL, "cough_featurize: NULL argument");
     COUGH_REQUIRE(n_clips >= 0 && n_samples >= 0, COUGH_EINVAL, "cough_featurize: n_clips < 0 or n_samples < 0");
-    if (!featurizer_tuned(f, n_samples)) {
+    const int route = featurizer_route(f, n_samples);
+    const bool geo_launch = route == 3 || (route == 1 && f->kind == 3);   // the run-time-geometry instantiation runs
+    if (route == 0) {
         COUGH_REQUIRE(!stem, COUGH_EUNSUPPORTED, "the fused stem needs the shipped 90-row feature layout");
         if (n_clips == 0) return COUGH_OK;
         return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, n_samples, d_feat, f->nfeat, f->nbase, n_clips,
                              (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0, d_workspace, workspace_bytes, stream);
     }
-    if (f->kind == 3)
-        COUGH_REQUIRE(wav_stride >= f->cfg.segment_samples, COUGH_EINVAL, "cough_featurize: row stride %lld < segment of %d samples",
-                      wav_stride, f->cfg.segment_samples);
+    const int n_wave = route == 3 ? n_samples : f->cfg.segment_samples;   // samples per clip of this launch
+    if (geo_launch)
+        COUGH_REQUIRE(wav_stride >= n_wave, COUGH_EINVAL, "cough_featurize: row stride %lld < %d samples", wav_stride, n_wave);
     else
         COUGH_REQUIRE(wav_stride >= NS && (wav_stride & 3) == 0 && (reinterpret_cast<size_t>(d_wav) & 15) == 0,
                       COUGH_EINVAL, "cough_featurize: d_wav must be 16-byte aligned with a row stride >= 16000, multiple of 4");
-    COUGH_REQUIRE(!stem || featurizer_stem_fusable(f, stem->x3 != 0), COUGH_EUNSUPPORTED,
+    COUGH_REQUIRE(!stem || (route == 1 && featurizer_stem_fusable(f, stem->x3 != 0)), COUGH_EUNSUPPORTED,
                   "the fused stem needs the shipped 90-row feature layout");
     if (n_clips == 0) return COUGH_OK;
     const int norm = (flags & COUGH_FEAT_NORMALIZE) ? 1 : 0;
@@ -1367,7 +1392,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
     const FullBank nofb{};
     // spectral-contrast rows under the fused normalise: the featurise kernel leaves every clip's peak for the contrast path
     float* peak_out = nullptr;
-    if (f->contrast.n_bands > 0 && norm && f->kind != 3) {
+    if (f->contrast.n_bands > 0 && norm && !geo_launch) {
         COUGH_REQUIRE(d_workspace && workspace_bytes >= contrast_workspace_bytes(n_clips), COUGH_EWORKSPACE,
                       "spectral contrast needs a workspace of cough_featurizer_workspace_bytes() bytes (cough_featurize_ws)");
         peak_out = contrast_peaks(d_workspace, n_clips);
@@ -1379,9 +1404,14 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         peak_out = static_cast<float*>(d_workspace);
     }
     // one instantiation per (pre-emphasis, stem, full-band filterbank, 103-row stem); everything else is a run-time argument
-    const bool full = f->kind >= 2, pe = f->cfg.use_pre_emphasis != 0;
-    const size_t lds = full ? f->full_lds : LDS_TOTAL;
-    const FullBank& fbk = full ? f->full : nofb;
+    const bool full = f->kind >= 2 || geo_launch, pe = f->cfg.use_pre_emphasis != 0;
+    FullBank geo_bank = f->full;   // another waveform length: the same tables, its own frame count
+    if (route == 3) {
+        geo_bank.n_samples = n_samples;
+        geo_bank.n_frames = n_samples / f->cfg.hop_length + 1;
+    }
+    const size_t lds = route == 3 ? full_lds_bytes(geo_bank.n_mels, geo_bank.n_taps, geo_bank.n_frames) : full ? f->full_lds : LDS_TOTAL;
+    const FullBank& fbk = route == 3 ? geo_bank : full ? f->full : nofb;
     const float* fdct = full ? f->full.dct : nullptr;
     auto go = [&](auto kernel, const StemFuse& sf, int pcen) {
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, d_wav, wav_stride, d_feat, f->nfeat, f->d_tables, norm,
@@ -1402,7 +1432,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         }
     } else if (stem) {        // approximate single-bf16 stem: shipped filterbank, no pre-emphasis (featurizer_stem_fusable)
         go(featurize_kernel<false, 1>, *stem, 0);
-    } else if (f->kind == 3) {   // run-time STFT geometry
+    } else if (geo_launch) {   // run-time STFT geometry
         if (pe) go(featurize_kernel<true, 0, true, false, false, true>, none, f->cfg.use_pcen);
         else go(featurize_kernel<false, 0, true, false, false, true>, none, f->cfg.use_pcen);
     } else if (full) {
@@ -1413,7 +1443,7 @@ int launch_featurize(const cough_featurizer* f, const float* d_wav, long long wa
         else go(featurize_kernel<false, 0>, none, f->cfg.use_pcen);
     }
     COUGH_HIP_CHECK(hipGetLastError());
-    if (f->contrast.n_bands > 0 && f->kind == 3)   // run-time geometry: the generic chain's STFT + contrast kernels add the rows
+    if (f->contrast.n_bands > 0 && geo_launch)   // run-time geometry: the generic chain's STFT + contrast kernels add the rows
         return gen_featurize(f->gen, f->cfg, f->contrast, d_wav, wav_stride, n_samples, d_feat, f->nfeat, f->nbase, n_clips, norm,
                              d_workspace, workspace_bytes, stream, /*contrast_rows_only=*/true);
     if (f->contrast.n_bands > 0)   // rows [nbase, nfeat): from the un-emphasised signal (preprocessing.py:476-478)

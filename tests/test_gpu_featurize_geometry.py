@@ -88,7 +88,7 @@ def test_runtime_geometry_against_oracle(name):
         assert torch.all(got[7, :nm] == 0)
         # batch invariance: every reduction is per clip
         assert torch.equal(pre.featurize_batch(w[3:4].cuda(), normalize=normalize)[0], got[3])
-    # another length through the same handle goes down the generic chain and comes back (the length is a launch parameter)
+    # another length through the same handle (the length is a launch parameter of the same kernel, or the generic chain's)
     other = torch.from_numpy(np.stack([geometry_clip(s, n + 300) for s in (0, 1)]))
     f2 = pre.extract_features(other.cuda())
     mel, rel = _errors(f2, ofeat.extract_features_batch(other, **kw), nm)
@@ -268,3 +268,32 @@ def test_raw_c_abi_argument_errors_on_the_runtime_geometry_path():
     assert rc == _lib.EINVAL and b"stride" in lib.cough_amd_last_error()
     assert call(flags_=0) == _lib.OK                                      # without normalize the peaks are not needed: still fine
     assert call() == _lib.OK and torch.equal(out, good)                   # and the handle is unharmed
+
+
+def test_other_waveform_lengths_through_one_handle_take_the_one_launch_kernel_too():
+    """extract_features never checks the length (/root/reference/src/preprocessing.py:432-489).  A handle built for the shipped
+    1 s segment featurises other lengths with the run-time-geometry instantiation when they fit its limits (here: up to ~2.2 s of
+    64 bands) and with the generic chain beyond; results vs the oracle either way, flags included, and the segment's own kernel is
+    untouched in between."""
+    from cough_detector_amd import _lib
+    for flags in (SHIPPED, {**SHIPPED, "use_pre_emphasis": True, "use_delta_delta": True},
+                  {**SHIPPED, "use_spectral_contrast": True, "n_contrast_bands": 3}, {**SHIPPED, "use_pcen": True}):
+        pre = cda.AudioPreprocessor(device="cuda", **BASE, **flags)
+        assert pre.kernel_path() == "tuned"
+        lib, h = _lib.load(), pre._native()
+        one = torch.from_numpy(geometry_clip(3, 16000))[None]
+        base = pre.featurize_batch(one.cuda(), normalize=True)
+        for n in (8000, 12345, 16001, 30000, 257, 48000):
+            w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in (0, 4, 5)]))
+            need = lib.cough_featurizer_workspace_bytes_for(h, n, 3)
+            one_launch = n // 160 + 1 <= (208 if flags.get("use_pcen") else 222)
+            if not flags.get("use_spectral_contrast"):
+                assert (need == 0) == one_launch, (n, need)              # the generic chain always needs scratch
+            got = pre.featurize_batch(w.cuda(), normalize=True).cpu()
+            ref = ofeat.extract_features_batch(w, normalize_first=True, **ofeat.geometry_kwargs(**BASE), **flags)
+            assert got.shape == ref.shape == (3, pre.get_num_features(), n // 160 + 1)
+            nbase = got.shape[1] - (4 if flags.get("use_spectral_contrast") else 0)
+            mel, rel = _errors(got[:, :nbase], ref[:, :nbase], 64)
+            cerr = (got[:, nbase:] - ref[:, nbase:]).abs().max().item() if nbase < got.shape[1] else 0.0
+            assert mel < FEAT_TOL and rel < 2 * FEAT_TOL and cerr < 2e-4, (flags, n, mel, rel, cerr)
+        assert torch.equal(pre.featurize_batch(one.cuda(), normalize=True), base)

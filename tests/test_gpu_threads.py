@@ -151,7 +151,9 @@ def test_two_threads_share_one_preprocessor_that_needs_scratch(kw):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
-    assert results == [True, True] and len(pre._ws) >= 2        # one scratch buffer per stream
+    assert results == [True, True]
+    if "n_fft" in kw or kw.get("use_spectral_contrast"):        # (the one-launch kernels need no scratch without contrast rows, at
+        assert len(pre._ws) >= 2                                #  any waveform length they take): one scratch buffer per stream
 
 
 def test_realtime_queue_detector_is_the_reference_consumer_loop(tmp_path):
