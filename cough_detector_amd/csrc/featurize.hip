@@ -561,35 +561,52 @@ __global__ __launch_bounds__(THREADS, GEO ? COUGH_GEO_WG_PER_CU : 3) void featur
     [[maybe_unused]] float pcv[PCS ? 26 : 1];
     K1_MARK("SKIP PCEN branch (off in the shipped configuration)");
     if (GEO && pcen) {
-        // Run-time frame count (<= 208): thread = (band, quarter of the frames) walks its quarter in up to two chunks of 26 frames
-        // -- the body of the fixed-geometry branch below -- and keeps the values in registers (two workgroups per CU: 256 VGPRs)
-        // until the clip's minimum and maximum are known.
-        // Up to 64 bands: the threads of a band past the last one idle (an empty frame range; they read band 0).
-        const int mt = tid >> 2, m = mt < nmel ? mt : 0, quarter = (NF + 3) >> 2;
-        const int q0 = (tid & 3) * quarter, q1 = mt >= nmel ? q0 : q0 + quarter < NF ? q0 + quarter : NF;
+        // Run-time frame count (<= 208) and band count (<= 128): thread = (band, quarter of the frames) walks its quarter in up to
+        // two chunks of 26 frames -- the body of the fixed-geometry branch below.  Bands 0..63 keep their values in registers (two
+        // workgroups per CU: 256 VGPRs) until the clip's minimum and maximum are known; bands 64..127 (a second round) leave theirs
+        // un-normalised in the output rows and the same thread rescales them there.  Threads of a band past the last one idle (an
+        // empty frame range; they read band 0).
+        const int mt = tid >> 2, quarter = (NF + 3) >> 2;
+        const int q0 = (tid & 3) * quarter;
         float lmin = INFINITY, lmax = -INFINITY;
-        float pv[2][26];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        // chunk c of band mm: values of frames q0 + 26 c + k; [q0, qe) is the thread's live frame range
+        auto pcen_chunk = [&](int mm, int c, int qe, float (&pv)[26]) {
             const int t0 = q0 + 26 * c;
-            if (c == 0 || quarter > 26) {   // workgroup-uniform
-                float p[36], s2[35];
+            float p[36], s2[35];
 #pragma unroll
-                for (int k = 0; k < 36; ++k) {
-                    const int u = t0 - 5 + k;
-                    p[k] = (u >= 0 && u < NF) ? exp2f((melbuf[m * NF + u] - shift) * 0.33219280948873623f) : 0.f;
+            for (int k = 0; k < 36; ++k) {
+                const int u = t0 - 5 + k;
+                p[k] = (u >= 0 && u < NF) ? exp2f((melbuf[mm * NF + u] - shift) * 0.33219280948873623f) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 35; ++k) s2[k] = p[k] + p[k + 1];
+#pragma unroll
+            for (int k = 0; k < 26; ++k) {
+                const float sm = ((s2[k] + s2[k + 2]) + (s2[k + 4] + s2[k + 6])) + s2[k + 8];
+                const float gain = __builtin_amdgcn_exp2f(-0.98f * __builtin_amdgcn_logf(1e-6f + sm * 0.1f));
+                pv[k] = __builtin_amdgcn_sqrtf(fmaf(p[k + 5], gain, 2.0f)) - 1.41421356237309515f;
+                if (t0 + k < qe) {
+                    lmin = fminf(lmin, pv[k]);
+                    lmax = fmaxf(lmax, pv[k]);
                 }
+            }
+        };
+        const int m = mt < nmel ? mt : 0;
+        const int q1 = mt >= nmel ? q0 : q0 + quarter < NF ? q0 + quarter : NF;
+        float pv[2][26];
+        pcen_chunk(m, 0, q1, pv[0]);
+        if (quarter > 26) pcen_chunk(m, 1, q1, pv[1]);   // workgroup-uniform
+        const int m2 = mt + 64 < nmel ? mt + 64 : 0;
+        const int q2 = mt + 64 >= nmel ? q0 : q0 + quarter < NF ? q0 + quarter : NF;
+        if (nmel > 64) {   // workgroup-uniform: the second round
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) {
+                if (c == 0 || quarter > 26) {
+                    float pw[26];
+                    pcen_chunk(m2, c, q2, pw);
 #pragma unroll
-                for (int k = 0; k < 35; ++k) s2[k] = p[k] + p[k + 1];
-#pragma unroll
-                for (int k = 0; k < 26; ++k) {
-                    const float sm = ((s2[k] + s2[k + 2]) + (s2[k + 4] + s2[k + 6])) + s2[k + 8];
-                    const float gain = __builtin_amdgcn_exp2f(-0.98f * __builtin_amdgcn_logf(1e-6f + sm * 0.1f));
-                    pv[c][k] = __builtin_amdgcn_sqrtf(fmaf(p[k + 5], gain, 2.0f)) - 1.41421356237309515f;
-                    if (t0 + k < q1) {
-                        lmin = fminf(lmin, pv[c][k]);
-                        lmax = fmaxf(lmax, pv[c][k]);
-                    }
+                    for (int k = 0; k < 26; ++k)
+                        if (q0 + 26 * c + k < q2) o[m2 * NF + q0 + 26 * c + k] = pw[k];
                 }
             }
         }
@@ -600,6 +617,7 @@ __global__ __launch_bounds__(THREADS, GEO ? COUGH_GEO_WG_PER_CU : 3) void featur
 #pragma unroll
             for (int k = 0; k < 26; ++k)
                 if (q0 + 26 * c + k < q1) o[m * NF + q0 + 26 * c + k] = (pv[c][k] - mn) * rng;
+        for (int t = q0; t < q2; ++t) o[m2 * NF + t] = (o[m2 * NF + t] - mn) * rng;
         wr_mel = false;
     } else
     if (pcen) {
@@ -1097,7 +1115,7 @@ namespace {
 // What the run-time-geometry instantiations (featurize_kernel<..., GEO>) take, whatever the waveform length ...
 bool geo_basic(const cough_feat_config& c) {
     return c.n_fft == NFFT && c.win_length >= 1 && c.win_length <= NFFT && c.hop_length >= 1 && c.n_mels >= 2 && c.n_mels <= 128 &&
-           (!c.use_mfcc || (c.n_mfcc >= 1 && c.n_mfcc <= c.n_mels)) && (!c.use_pcen || c.n_mels <= NMEL);
+           (!c.use_mfcc || (c.n_mfcc >= 1 && c.n_mfcc <= c.n_mels));
 }
 // ... and for waveforms of n samples.  The frames' 512-sample spans must cover every sample (the fused normalise collects the peak
 // from them): always so for hop <= 256, for a hop up to 512 when the last span reaches the end of the waveform.  PCEN: a thread keeps
@@ -1142,7 +1160,7 @@ extern "C" int cough_featurizer_create(cough_featurizer** out, const cough_feat_
     // kind 3: the full-band kernel with a run-time STFT geometry at n_fft = 512 -- other sample rates / hops / windows / segment
     // lengths (geo_basic / geo_fits above), and at the shipped STFT what the fixed-geometry full-band kernels do not take: an odd
     // number of mel bands (they store the mel rows in pairs), more than 20 MFCCs (they keep MFCC and delta rows side by side in the
-    // scratch), PCEN with fewer than 64 bands.  Contrast rows come from the generic chain's kernels behind it.
+    // scratch), PCEN with another band count than 64.  Contrast rows come from the generic chain's kernels behind it.
     const int geo_frames = cfg->hop_length > 0 ? cfg->segment_samples / cfg->hop_length + 1 : 0;
     const bool basic = geo_basic(*cfg);
     if (basic) {   // the CSR tables: for kinds 2 and 3, and for waveforms of other lengths on any kind

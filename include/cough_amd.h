@@ -104,7 +104,7 @@ int cough_featurizer_num_frames(const cough_featurizer* f);   /* get_expected_ti
 #define COUGH_PATH_TUNED_GEOMETRY 3 /* one launch, run-time STFT geometry: n_fft 512, any window, hop <= 256 (<= 512 while the
                                      * frames' spans still cover the segment), segments whose
                                      * n_mels x frames dB buffer fits the LDS (64 bands: ~220 frames; other sample rates / window
-                                     * durations), any filterbank -- also odd band counts, more than 20 MFCCs and PCEN with fewer than 64 bands at the shipped STFT, while
+                                     * durations), any filterbank -- also odd band counts, more than 20 MFCCs and PCEN with another band count than 64 at the shipped STFT, while
                                      * n_mfcc x frames x 4 <= 16 640 B --; spectral-contrast rows are added by the generic STFT kernel behind it
                                      * (needs the workspace) */
 int cough_featurizer_path(const cough_featurizer* f);

@@ -50,11 +50,11 @@ def test_which_constructor_calls_land_on_which_kernels():
     assert path(f_max=8000.0, use_pcen=True, use_pre_emphasis=True, use_delta_delta=True) == "tuned_fullband"
     assert path(f_max=8000.0, use_spectral_contrast=True, n_contrast_bands=4) == "tuned_fullband"
     assert path(f_max=8000.0, use_mfcc=False, n_mfcc=40) == "tuned_fullband"          # n_mfcc unused without MFCC rows
-    # odd band counts / more than 20 MFCCs: the run-time-geometry kernel; outside: PCEN off 64 bands, other n_fft
+    # odd band counts / more than 20 MFCCs / PCEN off 64 bands: the run-time-geometry kernel; outside: other n_fft
     assert path(n_mels=63, f_max=8000.0) == "tuned_geometry"      # odd band counts: the run-time-geometry kernel (element-wise stores)
     assert path(n_mels=80, n_mfcc=21, f_max=8000.0) == "tuned_geometry" and path(n_mels=128, n_mfcc=40, f_max=8000.0) == "tuned_geometry"
     assert path(n_mfcc=42) == "generic"                           # 42 x 101 MFCC values do not fit the 16 640-byte scratch
-    assert path(n_mels=80, f_max=8000.0, use_pcen=True) == "generic"
+    assert path(n_mels=80, f_max=8000.0, use_pcen=True) == "tuned_geometry"   # PCEN off 64 bands: the run-time-geometry kernel
     # n_fft = 512 with another hop / window / sample rate / segment of <= 128 frames: the full-band kernel with a run-time geometry
     assert path(hop_length=200) == "tuned_geometry" and path(segment_duration=0.5) == "tuned_geometry"
     assert path(sample_rate=22050, f_max=8000.0, hop_length=220, win_length=441) == "tuned_geometry"

@@ -105,14 +105,16 @@ def test_runtime_geometry_against_oracle(name):
                               "contrast1_wide_band_no_mfcc"])
 @pytest.mark.parametrize("name", ["half_second", "sr22050_hop220_win441", "hop128_win512_126_frames", "odd_hop77_win37_20mel",
                                   "two_seconds_201_frames", "odd_63_mel_bands_at_the_shipped_stft", "hop200_40mel",
-                                  "mel80_mfcc20_hop200"])
+                                  "mel80_mfcc20_hop200", "mel128_mfcc40_torchaudio_default_count", "odd_101_mel_bands_fmax8k"])
 def test_runtime_geometry_flags(name, flags):
     pre, g = _make(name, **flags)
     kw = {**SHIPPED, **flags}
     n, nm = pre.segment_samples, g["n_mels"]
     T = 1 + n // g["hop_length"]
-    # PCEN: thread = band x quarter of the frames, up to 64 bands; more bands take the generic chain
-    want = "generic" if flags.get("use_pcen") and nm > 64 else "tuned_geometry"
+    # never the generic chain (PCEN: thread = band x quarter of the frames, bands 64..127 in a second round); at the shipped STFT a flag
+    # set the fixed-geometry full-band kernel takes (e.g. no MFCC rows with 128 bands) stays there
+    shipped_stft = all(k in ("n_mels", "n_mfcc", "f_min", "f_max") for k in GEO[name][0]) and GEO[name][1] == 1.0
+    want = pre.kernel_path() if shipped_stft and pre.kernel_path() == "tuned_fullband" else "tuned_geometry"
     assert pre.kernel_path() == want
     w = torch.from_numpy(np.stack([geometry_clip(s, n) for s in range(6)]))
     got = pre.featurize_batch(w.cuda(), normalize=True)
@@ -135,8 +137,9 @@ def test_what_stays_on_the_generic_chain():
     assert path(2.0, n_mfcc=21, n_mels=40) == "generic"                                          # 21 x 201 MFCC values > 16 640 B
     assert path(hop_length=200, use_spectral_contrast=True, n_contrast_bands=3) == "tuned_geometry"   # rows [0, nbase) in one launch
     assert path(hop_length=200, n_mels=129, f_max=8000.0) == "generic" and path(hop_length=200, n_mfcc=52) == "generic"   # 52 x 81 x 4 B
-    assert path(n_mels=80, f_max=8000.0, hop_length=200, use_pcen=True) == "generic"             # PCEN: up to 64 bands
+    assert path(n_mels=80, f_max=8000.0, hop_length=200, use_pcen=True) == "tuned_geometry"
     assert path(n_mels=40, use_pcen=True) == "tuned_geometry" and path(n_mels=63, use_pcen=True) == "tuned_geometry"
+    assert path(2.2, use_pcen=True) == "generic"                                                 # PCEN: up to 208 frames
     assert path(n_fft=256, win_length=256) == "generic" and path(n_fft=1024) == "generic"
     assert path(hop_length=126, win_length=512, n_mels=128, n_mfcc=16, f_max=8000.0) == "generic"     # 64 KB of mel rows in LDS
     assert path(hop_length=126, win_length=512, n_mfcc=20, f_max=8000.0) == "tuned_geometry"
