@@ -22,10 +22,12 @@
 //   P2  block max -> top_db floor -> mel rows out (or PCEN); DCT with wave-uniform (scalar) coefficients; mean / unbiased std;
 //       z-score, deltas out; STEM: bf16 hi / lo feature images in LDS -> conv7x7 + BN + ReLU + maxpool on the matrix cores
 //
-// Template parameters (21 instantiations): PRE_EMPH (pre-emphasis while loading), STEM (0 none / 1 bf16 / 2 split-bf16 stem
+// Template parameters (23 instantiations): PRE_EMPH (pre-emphasis while loading), STEM (0 none / 1 bf16 / 2 split-bf16 stem
 // fused), FULL (full-band: all 257 bins, CSR filterbank in LDS, run-time n_mels / n_mfcc; otherwise the shipped sparse bank:
 // <= 8 register taps per band below bin 128, only bins 0..127 formed), TALL (103-row delta-delta image, stem in two halves),
-// PCS (PCEN values feed the stem).
+// PCS (PCEN values feed the stem), GEO (run-time STFT geometry at n_fft 512: hop, window, waveform length and frame count are
+// kernel arguments -- other sample rates / hops / windows / segment durations, waveforms of other lengths through any handle, and
+// the filterbanks the fixed-geometry kernels do not take: odd band counts, more than 20 MFCCs, PCEN off 64 bands).
 #include <cmath>
 #include <cstddef>
 #include <cstring>
