@@ -16,6 +16,7 @@ from cough_detector_amd.hostcpu import bound_torch_threads
 bound_torch_threads()
 warnings.simplefilter("ignore")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""      # substring filter on the case name (for a rocprofv3 run of one case)
 OFF = dict(use_pcen=False, use_pre_emphasis=False, use_delta_delta=False, use_spectral_contrast=False)
 CASES = [("shipped flags (90 rows)", OFF),
          ("delta-delta (103 rows)", dict(OFF, use_delta_delta=True)),
@@ -40,6 +41,8 @@ def timed(fn, n=20, warm=5):
 
 
 for name, kw in CASES:
+    if ONLY not in name:
+        continue
     pre = cda.AudioPreprocessor(device="cuda", **kw)
     rows = pre.get_num_features()
     w = torch.randn(B, pre.segment_samples, device="cuda") * 0.1
