@@ -306,3 +306,38 @@ def test_runtime_geometry_featuriser_random_stft_geometries():
         assert mel < 1e-4 and rel < 2e-4 and cerr < 2e-4, (case, g, flags, n, T, normalize, pre.kernel_path(), mel, rel, cerr)
     print(f"run-time geometry fuzz: {paths}")
     assert paths["tuned_geometry"] >= 30
+
+
+def test_random_waveform_lengths_through_random_handles():
+    """extract_features of any length (/root/reference/src/preprocessing.py:432-489 never checks it) through handles of random
+    n_fft-512 configurations: lengths that fit the run-time-geometry kernel's limits take it, the others the generic chain --
+    every result against the CPU oracle, and the handle's own segment is unharmed in between."""
+    from test_oracle_featurizer import geometry_clip
+    import os
+    rng = np.random.default_rng(int(os.environ.get("COUGH_FUZZ_SEED", "707")))      # tools/soak_any_length.sh: more seeds / cases
+    for case in range(int(os.environ.get("COUGH_FUZZ_CASES", "12"))):
+        n_mels = int(rng.choice([20, 40, 63, 64, 64, 64, 80, 128]))
+        n_mfcc = int(rng.integers(1, min(n_mels, 30) + 1))
+        hop = int(rng.choice([100, 128, 160, 160, 160, 200, 256, 300]))
+        win = int(rng.choice([256, 400, 400, 512]))
+        f_max = float(rng.choice([3000.0, 4000.0, 8000.0]))
+        flags = dict(use_pre_emphasis=bool(rng.integers(2)), use_delta_delta=bool(rng.integers(2)), use_pcen=bool(rng.integers(3) == 0),
+                     use_mfcc=bool(rng.integers(4) > 0), use_spectral_contrast=bool(rng.integers(4) == 0),
+                     n_contrast_bands=int(rng.integers(1, 5)))
+        g = dict(sample_rate=16000, n_mels=n_mels, n_fft=512, hop_length=hop, win_length=win, f_min=100.0, f_max=f_max, n_mfcc=n_mfcc)
+        pre = cda.AudioPreprocessor(device="cuda", **g, **flags)
+        seg = torch.from_numpy(np.stack([geometry_clip(case, 16000)]))
+        base = pre.featurize_batch(seg.cuda(), normalize=True)
+        kw = ofeat.geometry_kwargs(**g)
+        for n in [int(v) for v in rng.integers(257, 45000, size=3)]:
+            w = torch.from_numpy(np.stack([geometry_clip(case + s, n) for s in range(3)]))
+            normalize = bool(rng.integers(2))
+            f = pre.featurize_batch(w.cuda(), normalize=normalize).cpu()
+            ref = ofeat.extract_features_batch(w, normalize_first=normalize, **kw, **flags)
+            assert f.shape == ref.shape == (3, pre.get_num_features(), n // hop + 1), (case, g, flags, n)
+            nbase = f.shape[1] - (flags["n_contrast_bands"] + 1 if flags["use_spectral_contrast"] else 0)
+            mel = (f[:, :n_mels] - ref[:, :n_mels]).abs().max().item()
+            rel = ((f[:, n_mels:nbase] - ref[:, n_mels:nbase]).abs() / ref[:, n_mels:nbase].abs().clamp(min=1.0)).max().item() if nbase > n_mels else 0.0
+            cerr = (f[:, nbase:] - ref[:, nbase:]).abs().max().item() if flags["use_spectral_contrast"] else 0.0
+            assert mel < 1e-4 and rel < 2e-4 and cerr < 2e-4, (case, g, flags, n, normalize, pre.kernel_path(), mel, rel, cerr)
+        assert torch.equal(pre.featurize_batch(seg.cuda(), normalize=True), base), (case, g, flags)
