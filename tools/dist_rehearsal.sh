@@ -1,7 +1,7 @@
 #!/bin/bash
-# one-GPU rehearsal of everything multi-rank that CAN run on one card (r04 verdict item 1)
+# one-GPU rehearsal of everything multi-rank that CAN run on one card: 1 RCCL rank, 2 gloo ranks sharing the card, the --gpus 2 parent
 set -e
-OUT=gpurun_out/r04
+OUT=gpurun_out/r05/dist
 mkdir -p $OUT
 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_bench_line.py tests/test_gpu_stream_job.py -m gpu -q -rs > $OUT/pytest_multirank.txt 2>&1
 COUGH_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
